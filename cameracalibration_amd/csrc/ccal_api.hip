@@ -1,0 +1,806 @@
+// ccal_api.hip -- C ABI of the calibration hot path (see include/ccal.h).
+//
+// Host orchestration only: pose matrices and grid tables are prepared in FP64 on
+// the host (sines/cosines from libm, as the reference's Eigen calls do), every
+// per-point loop runs in the HIP kernels of kernels.hip.hpp.  There is no CPU
+// fallback: a missing or failing device is reported, never worked around.
+#include "ccal_internal.hpp"
+#include "kernels.hip.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+using namespace ccal;
+
+namespace {
+
+int fail(ccal_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define CCAL_HIP(ctx, expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail((ctx), CCAL_ERR_DEVICE,                                          \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));             \
+    } while (0)
+
+int bind(ccal_ctx* ctx)
+{
+    CCAL_HIP(ctx, hipSetDevice(ctx->device));
+    return CCAL_OK;
+}
+
+int check_set(ccal_ctx* ctx, int which)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (which != CCAL_DOWNSAMPLED && which != CCAL_RAW)
+        return fail(ctx, CCAL_ERR_ARG, "cloud-set selector must be CCAL_DOWNSAMPLED or CCAL_RAW");
+    if (!ctx->sets[which].ready) return fail(ctx, CCAL_ERR_STATE, "cloud set not uploaded");
+    return CCAL_OK;
+}
+
+constexpr int kPointsPerBlock = 256 * 16;  // exact path: points handled by one block
+constexpr int kNA = 8;                      // candidate tiles per wave on the fast path
+constexpr int kCandPerBlock = 4 * kNA * 16; // 512
+constexpr unsigned kBandCap = 1u << 16;     // max near-minimum candidates re-scored
+constexpr float kBand = 1e-4f;              // relative band around the fast-path minimum
+
+// Rows 0..2 of base_T_flange_j * F(pose) for every cloud, [n_clouds][12].
+void pose_matrices(const CloudSet& cs, const double pose[6], double* mats)
+{
+    SinCos3 sc = sincos_of_pose(pose);
+    double R[9];
+    rotation_zyx(sc.s, sc.c, R);
+    for (int j = 0; j < cs.n_clouds; ++j)
+        compose_rows(cs.base_T_flange.data() + 16 * j, R, pose, mats + 12 * j);
+}
+
+template <int PB>
+void launch_exact(ccal_ctx* ctx, const CloudSet& cs)
+{
+    hipLaunchKernelGGL(exact_dist_kernel<PB>, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), cs.n_clouds, (int64_t)cs.total_pts,
+                       ctx->dist_buf.as<double>(), ctx->pmax_buf.as<double>());
+}
+
+int pick_pb(int n)
+{
+    static const int sizes[] = {1, 2, 4, 8, 13, 16, 21, 32};
+    for (int s : sizes)
+        if (n <= s) return s;
+    return 32;
+}
+
+void dispatch_exact(ccal_ctx* ctx, const CloudSet& cs, int pb)
+{
+    switch (pb) {
+    case 1: launch_exact<1>(ctx, cs); break;
+    case 2: launch_exact<2>(ctx, cs); break;
+    case 4: launch_exact<4>(ctx, cs); break;
+    case 8: launch_exact<8>(ctx, cs); break;
+    case 13: launch_exact<13>(ctx, cs); break;
+    case 16: launch_exact<16>(ctx, cs); break;
+    case 21: launch_exact<21>(ctx, cs); break;
+    default: launch_exact<32>(ctx, cs); break;
+    }
+}
+
+// Splits of the point stream so that the launch has enough blocks to fill the
+// chip several times over, without cutting a cloud into slivers.
+int choose_splits(const ccal_ctx* ctx, const CloudSet& cs, int64_t cand_blocks)
+{
+    const int64_t target = (int64_t)ctx->n_cu * 64;
+    int64_t s = (target + cand_blocks - 1) / cand_blocks;
+    int64_t s_max = std::max<int64_t>(1, cs.min_groups / 8);
+    s = std::min<int64_t>(s, s_max);
+    s = std::min<int64_t>(s, 64);
+    return (int)std::max<int64_t>(1, s);
+}
+
+struct FastLaunch {
+    int n_ctiles;
+    int64_t n_padded;
+    int64_t cand_blocks;
+    int n_splits;
+};
+
+FastLaunch plan_fast(const ccal_ctx* ctx, const CloudSet& cs, int64_t n)
+{
+    FastLaunch f;
+    f.cand_blocks = (n + kCandPerBlock - 1) / kCandPerBlock;
+    f.n_padded = f.cand_blocks * kCandPerBlock;
+    f.n_ctiles = (int)(f.n_padded / 16);
+    f.n_splits = choose_splits(ctx, cs, f.cand_blocks);
+    return f;
+}
+
+// Largest candidate chunk per launch: bounded by the W buffer (16 B per
+// candidate and cloud) and by the 2^31 tile index range.
+int64_t fast_chunk(const CloudSet& cs)
+{
+    const int64_t w_budget = (int64_t)4 << 30;  // 4 GiB of W per launch
+    int64_t c = w_budget / (16 * (int64_t)cs.n_clouds);
+    c = std::min<int64_t>(c, (int64_t)1 << 24);
+    c = std::max<int64_t>(c, kCandPerBlock);
+    return (c / kCandPerBlock) * kCandPerBlock;
+}
+
+FoldConsts fold_consts(const float plane[4])
+{
+    FoldConsts fc;
+    fc.n[0] = plane[0]; fc.n[1] = plane[1]; fc.n[2] = plane[2];
+    fc.d = plane[3];
+    fc.inv_norm = 1.0 / std::sqrt(fc.n[0] * fc.n[0] + fc.n[1] * fc.n[1] + fc.n[2] * fc.n[2]);
+    return fc;
+}
+
+// wgen + residual + split reduction for one chunk of candidates; costs go to
+// cost_dst[0..n).  ev0/ev1 (optional) bracket the residual kernel.
+template <typename Source>
+int run_fast_chunk(ccal_ctx* ctx, const CloudSet& cs, const Source& src, int64_t n,
+                   float* cost_dst, hipEvent_t ev0, hipEvent_t ev1)
+{
+    FastLaunch f = plan_fast(ctx, cs, n);
+    CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)cs.n_clouds * f.n_ctiles * 64 * sizeof(float)));
+    CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)f.n_splits * f.n_padded * sizeof(double)));
+    const FoldConsts fc = fold_consts(ctx->plane);
+    hipLaunchKernelGGL(wgen_kernel<Source>, dim3((unsigned)((f.n_padded + 255) / 256)), dim3(256),
+                       0, ctx->stream, src, n, f.n_ctiles, cs.n_clouds,
+                       cs.base_dev.as<double>(), cs.centres_dev.as<double>(), fc,
+                       ctx->w_buf.as<float>());
+    if (ev0) CCAL_HIP(ctx, hipEventRecord(ev0, ctx->stream));
+    hipLaunchKernelGGL(residual_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
+                       dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
+                       cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+                       cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
+                       f.n_ctiles, f.n_splits);
+    if (ev1) CCAL_HIP(ctx, hipEventRecord(ev1, ctx->stream));
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->partial_buf.as<double>(), f.n_padded, f.n_splits, n,
+                       cost_dst);
+    CCAL_HIP(ctx, hipGetLastError());
+    return CCAL_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------
+
+extern "C" int ccal_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* ccal_status_string(int status)
+{
+    switch (status) {
+    case CCAL_OK: return "ok";
+    case CCAL_ERR_ARG: return "invalid argument";
+    case CCAL_ERR_DEVICE: return "device error";
+    case CCAL_ERR_STATE: return "invalid state";
+    case CCAL_ERR_CAPACITY: return "capacity exceeded";
+    case CCAL_ERR_IO: return "i/o error";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int ccal_create(int device_id, ccal_ctx** out)
+{
+    if (!out) return CCAL_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CCAL_ERR_DEVICE;
+    if (device_id < 0 || device_id >= n) return CCAL_ERR_ARG;
+    ccal_ctx* ctx = new (std::nothrow) ccal_ctx;
+    if (!ctx) return CCAL_ERR_DEVICE;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return CCAL_ERR_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_destroy(ccal_ctx* ctx)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->sets) s.release();
+    DevBuf* bufs[] = {&ctx->w_buf, &ctx->partial_buf, &ctx->cost_buf, &ctx->rec_buf,
+                      &ctx->minrec_buf, &ctx->list_buf, &ctx->count_buf, &ctx->mats_buf,
+                      &ctx->planes_buf, &ctx->psum_buf, &ctx->pmax_buf, &ctx->osum_buf,
+                      &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf};
+    for (DevBuf* b : bufs) b->release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CCAL_OK;
+}
+
+extern "C" const char* ccal_last_error(const ccal_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : "null context";
+}
+
+extern "C" void ccal_pose_to_matrix(const double pose[6], double T[16])
+{
+    SinCos3 sc = sincos_of_pose(pose);
+    double R[9];
+    rotation_zyx(sc.s, sc.c, R);
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = pose[i];
+    }
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// upload
+// ---------------------------------------------------------------------------
+
+extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
+                                  const float* const* xyz, const size_t* n_pts,
+                                  const double* base_T_flange)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (which != CCAL_DOWNSAMPLED && which != CCAL_RAW)
+        return fail(ctx, CCAL_ERR_ARG, "cloud-set selector must be CCAL_DOWNSAMPLED or CCAL_RAW");
+    if (n_clouds <= 0 || !xyz || !n_pts || !base_T_flange)
+        return fail(ctx, CCAL_ERR_ARG, "upload: null or empty argument");
+    size_t total = 0;
+    for (int j = 0; j < n_clouds; ++j) {
+        if (n_pts[j] == 0 || !xyz[j])
+            return fail(ctx, CCAL_ERR_ARG, "upload: empty cloud (the objective divides by its size)");
+        total += n_pts[j];
+    }
+    if (total >= ((size_t)1 << 37)) return fail(ctx, CCAL_ERR_ARG, "upload: too many points");
+    if (int rc = bind(ctx)) return rc;
+
+    CloudSet& cs = ctx->sets[which];
+    cs.ready = false;
+    cs.n_clouds = n_clouds;
+    cs.n_pts.assign(n_pts, n_pts + n_clouds);
+    cs.base_T_flange.assign(base_T_flange, base_T_flange + 16 * (size_t)n_clouds);
+    cs.total_pts = total;
+
+    // ---- exact path: SoA + block table --------------------------------------
+    std::vector<float> hx(total), hy(total), hz(total);
+    std::vector<BlockDesc> blocks;
+    cs.cloud_block_off.assign(n_clouds + 1, 0);
+    size_t off = 0;
+    for (int j = 0; j < n_clouds; ++j) {
+        const float* p = xyz[j];
+        for (size_t i = 0; i < n_pts[j]; ++i) {
+            hx[off + i] = p[3 * i + 0];
+            hy[off + i] = p[3 * i + 1];
+            hz[off + i] = p[3 * i + 2];
+        }
+        cs.cloud_block_off[j] = (int)blocks.size();
+        for (size_t b = 0; b < n_pts[j]; b += kPointsPerBlock) {
+            BlockDesc bd;
+            bd.cloud = j;
+            bd.first_of_cloud = cs.cloud_block_off[j];
+            bd.begin = (int64_t)(off + b);
+            bd.end = (int64_t)(off + std::min(n_pts[j], b + (size_t)kPointsPerBlock));
+            blocks.push_back(bd);
+        }
+        off += n_pts[j];
+    }
+    cs.cloud_block_off[n_clouds] = (int)blocks.size();
+    cs.n_blocks = (int)blocks.size();
+
+    CCAL_HIP(ctx, cs.xs.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.ys.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.zs.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.blocks.ensure(blocks.size() * sizeof(BlockDesc)));
+    CCAL_HIP(ctx, cs.cloud_block_off_dev.ensure((n_clouds + 1) * sizeof(int)));
+    CCAL_HIP(ctx, hipMemcpy(cs.xs.p, hx.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.ys.p, hy.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.zs.p, hz.data(), total * sizeof(float), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.blocks.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.cloud_block_off_dev.p, cs.cloud_block_off.data(),
+                            (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
+    {
+        std::vector<int64_t> pt_off(n_clouds + 1, 0);
+        for (int j = 0; j < n_clouds; ++j) pt_off[j + 1] = pt_off[j] + (int64_t)n_pts[j];
+        CCAL_HIP(ctx, cs.cloud_pt_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
+        CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(),
+                                (n_clouds + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    hx.clear(); hx.shrink_to_fit();
+    hy.clear(); hy.shrink_to_fit();
+    hz.clear(); hz.shrink_to_fit();
+
+    // ---- fast path: centred 64-point groups ---------------------------------
+    cs.group_off.assign(n_clouds + 1, 0);
+    cs.centres.assign(3 * (size_t)n_clouds, 0.0);
+    int64_t n_groups = 0;
+    cs.min_groups = std::numeric_limits<int>::max();
+    for (int j = 0; j < n_clouds; ++j) {
+        cs.group_off[j] = (int)n_groups;
+        int64_t g = ((int64_t)n_pts[j] + kGroupPoints - 1) / kGroupPoints;
+        cs.min_groups = (int)std::min<int64_t>(cs.min_groups, g);
+        n_groups += g;
+    }
+    if (n_groups >= ((int64_t)1 << 31)) return fail(ctx, CCAL_ERR_ARG, "upload: too many points");
+    cs.group_off[n_clouds] = (int)n_groups;
+    cs.n_groups = n_groups;
+    cs.n_pad_points = n_groups * kGroupPoints - (int64_t)total;
+
+    std::vector<float> hg((size_t)n_groups * 256, 0.0f);
+    std::vector<double> scale(n_clouds);
+    for (int j = 0; j < n_clouds; ++j) {
+        const float* p = xyz[j];
+        const size_t n = n_pts[j];
+        double c[3] = {0, 0, 0};
+        for (size_t i = 0; i < n; ++i) {
+            c[0] += p[3 * i]; c[1] += p[3 * i + 1]; c[2] += p[3 * i + 2];
+        }
+        for (int k = 0; k < 3; ++k) {
+            c[k] /= (double)n;
+            if (!std::isfinite(c[k])) c[k] = 0.0;
+            cs.centres[3 * j + k] = c[k];
+        }
+        scale[j] = 1.0 / ((double)n_clouds * (double)n);
+        float* base = hg.data() + (size_t)cs.group_off[j] * 256;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t g = i / kGroupPoints;
+            const int in_group = (int)(i % kGroupPoints);
+            const int u = in_group / kTilePoints, col = in_group % kTilePoints;
+            float* gp = base + g * 256;
+            // lane l = k*16 + col holds coordinate k; component u selects the tile
+            gp[(0 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 0] - c[0]);
+            gp[(1 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 1] - c[1]);
+            gp[(2 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 2] - c[2]);
+            gp[(3 * 16 + col) * 4 + u] = 1.0f;
+        }
+    }
+    CCAL_HIP(ctx, cs.groups.ensure(hg.size() * sizeof(float)));
+    CCAL_HIP(ctx, cs.group_off_dev.ensure((n_clouds + 1) * sizeof(int)));
+    CCAL_HIP(ctx, cs.scale_dev.ensure(n_clouds * sizeof(double)));
+    CCAL_HIP(ctx, cs.centres_dev.ensure(3 * n_clouds * sizeof(double)));
+    CCAL_HIP(ctx, cs.base_dev.ensure(16 * (size_t)n_clouds * sizeof(double)));
+    CCAL_HIP(ctx, hipMemcpy(cs.groups.p, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.group_off_dev.p, cs.group_off.data(), (n_clouds + 1) * sizeof(int),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.scale_dev.p, scale.data(), n_clouds * sizeof(double),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.centres_dev.p, cs.centres.data(), 3 * n_clouds * sizeof(double),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.base_dev.p, cs.base_T_flange.data(),
+                            16 * (size_t)n_clouds * sizeof(double), hipMemcpyHostToDevice));
+    cs.ready = true;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_plane(ccal_ctx* ctx, const float plane[4])
+{
+    if (!ctx || !plane) return CCAL_ERR_ARG;
+    double n2 = (double)plane[0] * plane[0] + (double)plane[1] * plane[1] + (double)plane[2] * plane[2];
+    if (!(n2 > 0.0) || !std::isfinite(n2) || !std::isfinite(plane[3]))
+        return fail(ctx, CCAL_ERR_ARG, "plane normal must be finite and non-zero");
+    std::memcpy(ctx->plane, plane, 4 * sizeof(float));
+    ctx->plane_set = true;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_get_plane(const ccal_ctx* ctx, float plane[4])
+{
+    if (!ctx || !plane) return CCAL_ERR_ARG;
+    if (!ctx->plane_set) return CCAL_ERR_STATE;
+    std::memcpy(plane, ctx->plane, 4 * sizeof(float));
+    return CCAL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exact objective
+// ---------------------------------------------------------------------------
+
+int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                     const double* planes4, double* cost, double* per_cloud_mean,
+                     double* per_cloud_max)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost)))
+        return fail(ctx, CCAL_ERR_ARG, "eval: null argument");
+    if (!planes4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "eval: plane not set");
+    if (n_poses == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+
+    // poses per pass: bounded by the distance buffer (8 B per pose and point)
+    const int64_t dist_budget = (int64_t)8 << 30;
+    int max_batch = (int)std::min<int64_t>(32, std::max<int64_t>(1, dist_budget / (8 * (int64_t)cs.total_pts)));
+    std::vector<double> mats, planes, hsum, hmax;
+    for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const int nb = std::min(max_batch, n_poses - k0);
+        const int pb = pick_pb(nb);
+        mats.assign((size_t)pb * C * 12, 0.0);
+        planes.assign((size_t)pb * kPlaneStride, 0.0);
+        for (int k = 0; k < pb; ++k) {
+            const int src = k0 + (k < nb ? k : 0);  // padding slots repeat the first pose
+            pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data() + (size_t)k * C * 12);
+            double* pl = planes.data() + (size_t)k * kPlaneStride;
+            if (planes4) {
+                for (int e = 0; e < 4; ++e) pl[e] = planes4[4 * (size_t)src + e];
+            } else {
+                for (int e = 0; e < 4; ++e) pl[e] = (double)ctx->plane[e];
+            }
+            // sqrt(pow(a,2)+pow(b,2)+pow(c,2)) as at :123 / :128
+            pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+        }
+        CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
+        CCAL_HIP(ctx, ctx->planes_buf.ensure(planes.size() * sizeof(double)));
+        CCAL_HIP(ctx, ctx->dist_buf.ensure((size_t)pb * cs.total_pts * sizeof(double)));
+        CCAL_HIP(ctx, ctx->pmax_buf.ensure((size_t)cs.n_blocks * pb * sizeof(double)));
+        CCAL_HIP(ctx, ctx->osum_buf.ensure((size_t)pb * C * sizeof(double)));
+        CCAL_HIP(ctx, ctx->omax_buf.ensure((size_t)pb * C * sizeof(double)));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, planes.data(),
+                                     planes.size() * sizeof(double), hipMemcpyHostToDevice,
+                                     ctx->stream));
+        dispatch_exact(ctx, cs, pb);
+        const int n_chains = pb * C;
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3((n_chains + 63) / 64), dim3(64), 0,
+                           ctx->stream, ctx->dist_buf.as<double>(),
+                           cs.cloud_pt_off_dev.as<int64_t>(), n_chains, C,
+                           (int64_t)cs.total_pts, ctx->osum_buf.as<double>());
+        hipLaunchKernelGGL(exact_max_kernel, dim3(pb * C), dim3(64), 0, ctx->stream,
+                           ctx->pmax_buf.as<double>(), cs.cloud_block_off_dev.as<int>(), pb, C,
+                           ctx->omax_buf.as<double>());
+        CCAL_HIP(ctx, hipGetLastError());
+        hsum.resize((size_t)pb * C);
+        hmax.resize((size_t)pb * C);
+        CCAL_HIP(ctx, hipMemcpyAsync(hsum.data(), ctx->osum_buf.p, hsum.size() * sizeof(double),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        CCAL_HIP(ctx, hipMemcpyAsync(hmax.data(), ctx->omax_buf.p, hmax.size() * sizeof(double),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nb; ++k) {
+            double error = 0.0;
+            for (int j = 0; j < C; ++j) {
+                const double mean = hsum[(size_t)k * C + j] / (double)cs.n_pts[j];  // :309
+                error += mean;
+                if (per_cloud_mean) per_cloud_mean[(size_t)(k0 + k) * C + j] = mean;
+                if (per_cloud_max) per_cloud_max[(size_t)(k0 + k) * C + j] = hmax[(size_t)k * C + j];
+            }
+            cost[k0 + k] = error / (double)C;  // :312
+        }
+    }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                         const double* planes4, double* cost, double* per_cloud_mean,
+                         double* per_cloud_max)
+{
+    return ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean,
+                            per_cloud_max);
+}
+
+// ---------------------------------------------------------------------------
+// fast objective for explicit pose lists
+// ---------------------------------------------------------------------------
+
+extern "C" int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* poses6,
+                              float* cost)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost)))
+        return fail(ctx, CCAL_ERR_ARG, "eval_fast: null argument");
+    if (!ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "eval_fast: plane not set");
+    if (n_poses == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int64_t chunk = fast_chunk(cs);
+    std::vector<double> rec;
+    for (int64_t c0 = 0; c0 < n_poses; c0 += chunk) {
+        const int64_t n = std::min(chunk, n_poses - c0);
+        rec.resize((size_t)n * 9);
+        for (int64_t c = 0; c < n; ++c) {
+            const double* pose = poses6 + 6 * (size_t)(c0 + c);
+            SinCos3 sc = sincos_of_pose(pose);
+            double* r = rec.data() + 9 * (size_t)c;
+            for (int k = 0; k < 3; ++k) { r[k] = pose[k]; r[3 + k] = sc.s[k]; r[6 + k] = sc.c[k]; }
+        }
+        CCAL_HIP(ctx, ctx->rec_buf.ensure(rec.size() * sizeof(double)));
+        CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n * sizeof(float)));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->rec_buf.p, rec.data(), rec.size() * sizeof(double),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        PoseList src{ctx->rec_buf.as<double>()};
+        if (int rc = run_fast_chunk(ctx, cs, src, n, ctx->cost_buf.as<float>(), nullptr, nullptr))
+            return rc;
+        CCAL_HIP(ctx, hipMemcpyAsync(cost + c0, ctx->cost_buf.p, (size_t)n * sizeof(float),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CCAL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// grid
+// ---------------------------------------------------------------------------
+
+extern "C" void ccal_grid_default(ccal_grid* g)
+{
+    if (!g) return;
+    for (int k = 0; k < 3; ++k) { g->min[k] = -20; g->step[k] = 4; g->count[k] = 11; }
+    for (int k = 3; k < 6; ++k) { g->min[k] = -5; g->step[k] = 1; g->count[k] = 11; }
+}
+
+extern "C" int64_t ccal_grid_size(const ccal_grid* g)
+{
+    if (!g) return 0;
+    int64_t n = 1;
+    for (int k = 0; k < 6; ++k) {
+        if (g->count[k] <= 0) return 0;
+        n *= g->count[k];
+    }
+    return n;
+}
+
+static inline double grid_axis_value(const ccal_grid* g, const double base[6], int k, int i)
+{
+    const double v = g->min[k] + i * g->step[k];
+    if (k < 3) return base[k] + v / 1000.0;  // :540 transformation[k] + x/1000.0
+    return base[k] + v * 3.141592 / 180;     // helpers.hpp:275-278
+}
+
+extern "C" void ccal_grid_pose(const ccal_grid* g, const double base_pose[6], int64_t index,
+                               double pose[6])
+{
+    int idx[6];
+    for (int k = 5; k >= 0; --k) {
+        idx[k] = (int)(index % g->count[k]);
+        index /= g->count[k];
+    }
+    for (int k = 0; k < 6; ++k) pose[k] = grid_axis_value(g, base_pose, k, idx[k]);
+}
+
+extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indices)
+{
+    int best = -1;
+    for (int i = 0; i < n; ++i) {
+        if (indices[i] < 0) continue;
+        if (best < 0 || costs[i] < costs[best] ||
+            (costs[i] == costs[best] && indices[i] < indices[best]))
+            best = i;
+    }
+    return best;
+}
+
+extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
+                                const ccal_grid* g, int64_t begin, int64_t end,
+                                int64_t* best_index, double* best_cost, double best_pose[6],
+                                ccal_grid_stats* stats)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!base_pose || !g || !best_index || !best_cost || !best_pose)
+        return fail(ctx, CCAL_ERR_ARG, "grid_search: null argument");
+    if (!ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "grid_search: plane not set");
+    const int64_t total = ccal_grid_size(g);
+    if (total <= 0) return fail(ctx, CCAL_ERR_ARG, "grid_search: empty grid axis");
+    if (begin < 0 || end > total || begin > end)
+        return fail(ctx, CCAL_ERR_ARG, "grid_search: candidate range outside the grid");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    *best_index = -1;
+    *best_cost = 1e9;  // :531
+    std::memcpy(best_pose, base_pose, 6 * sizeof(double));
+    const int64_t n_local = end - begin;
+    if (n_local == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+
+    // per-axis tables (host FP64, libm sin/cos)
+    int tot_entries = 0;
+    for (int k = 0; k < 6; ++k) tot_entries += g->count[k];
+    std::vector<double> tbl((size_t)tot_entries * 2, 0.0);
+    CCAL_HIP(ctx, ctx->tbl_buf.ensure(tbl.size() * sizeof(double)));
+    GridTables gt;
+    {
+        size_t o = 0;
+        double* dbase = ctx->tbl_buf.as<double>();
+        for (int k = 0; k < 3; ++k) {
+            gt.t[k] = dbase + o;
+            for (int i = 0; i < g->count[k]; ++i) tbl[o + i] = grid_axis_value(g, base_pose, k, i);
+            o += g->count[k];
+        }
+        for (int k = 0; k < 3; ++k) {
+            gt.sn[k] = dbase + o;
+            gt.cs[k] = dbase + o + g->count[3 + k];
+            for (int i = 0; i < g->count[3 + k]; ++i) {
+                const double a = grid_axis_value(g, base_pose, 3 + k, i);
+                tbl[o + i] = std::sin(a);
+                tbl[o + g->count[3 + k] + i] = std::cos(a);
+            }
+            o += 2 * (size_t)g->count[3 + k];
+        }
+        for (int k = 0; k < 6; ++k) gt.count[k] = g->count[k];
+    }
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, tbl.data(), tbl.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_local * sizeof(float)));
+
+    const int64_t chunk = fast_chunk(cs);
+    const int n_chunks = (int)((n_local + chunk - 1) / chunk);
+    std::vector<hipEvent_t> evs((size_t)n_chunks * 2 + 2, nullptr);
+    for (auto& e : evs) CCAL_HIP(ctx, hipEventCreate(&e));
+    auto free_events = [&]() { for (auto& e : evs) if (e) (void)hipEventDestroy(e); };
+
+    CCAL_HIP(ctx, hipEventRecord(evs[2 * (size_t)n_chunks], ctx->stream));
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int64_t c0 = (int64_t)ci * chunk;
+        const int64_t n = std::min(chunk, n_local - c0);
+        gt.first = begin + c0;
+        if (int rc = run_fast_chunk(ctx, cs, gt, n, ctx->cost_buf.as<float>() + c0, evs[2 * ci],
+                                    evs[2 * ci + 1])) {
+            free_events();
+            return rc;
+        }
+    }
+
+    // arg-min and near-minimum band over the local cost array
+    const int n_stage1 = (int)std::min<int64_t>(1024, (n_local + 255) / 256);
+    CCAL_HIP(ctx, ctx->minrec_buf.ensure((size_t)(n_stage1 + 1) * sizeof(MinRec)));
+    CCAL_HIP(ctx, ctx->list_buf.ensure((size_t)kBandCap * sizeof(int64_t)));
+    CCAL_HIP(ctx, ctx->count_buf.ensure(sizeof(unsigned int)));
+    MinRec* recs = ctx->minrec_buf.as<MinRec>();
+    CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(argmin_stage1_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
+                       ctx->cost_buf.as<float>(), n_local, recs);
+    hipLaunchKernelGGL(argmin_stage2_kernel, dim3(1), dim3(256), 0, ctx->stream, recs, n_stage1,
+                       recs + n_stage1);
+    hipLaunchKernelGGL(select_band_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
+                       ctx->cost_buf.as<float>(), n_local, recs + n_stage1, kBand,
+                       ctx->list_buf.as<int64_t>(), kBandCap, ctx->count_buf.as<unsigned int>());
+    CCAL_HIP(ctx, hipGetLastError());
+    CCAL_HIP(ctx, hipEventRecord(evs[2 * (size_t)n_chunks + 1], ctx->stream));
+
+    MinRec mn;
+    unsigned int n_band = 0;
+    CCAL_HIP(ctx, hipMemcpyAsync(&mn, recs + n_stage1, sizeof mn, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    CCAL_HIP(ctx, hipMemcpyAsync(&n_band, ctx->count_buf.p, sizeof n_band, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    double kernel_ms = 0.0;
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, evs[2 * ci], evs[2 * ci + 1]) == hipSuccess) kernel_ms += ms;
+    }
+    float total_ms = 0.f;
+    (void)hipEventElapsedTime(&total_ms, evs[2 * (size_t)n_chunks], evs[2 * (size_t)n_chunks + 1]);
+    free_events();
+
+    if (!(mn.cost < std::numeric_limits<float>::infinity()) || mn.index < 0)
+        return fail(ctx, CCAL_ERR_DEVICE, "grid_search: non-finite costs on the fast path");
+    if (n_band > kBandCap)
+        return fail(ctx, CCAL_ERR_CAPACITY,
+                    "grid_search: more near-minimum candidates than the re-score list holds");
+    std::vector<int64_t> list(n_band);
+    CCAL_HIP(ctx, hipMemcpy(list.data(), ctx->list_buf.p, (size_t)n_band * sizeof(int64_t),
+                            hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end());
+
+    // re-score the band with the reference arithmetic; strict '<' in index order
+    std::vector<double> poses((size_t)n_band * 6), exact(n_band);
+    for (unsigned i = 0; i < n_band; ++i)
+        ccal_grid_pose(g, base_pose, begin + list[i], poses.data() + 6 * (size_t)i);
+    if (int rc = ccal::eval_exact(ctx, which, (int)n_band, poses.data(), nullptr, exact.data(),
+                                  nullptr, nullptr))
+        return rc;
+    double error_min = 1e9;
+    int64_t best = -1;
+    for (unsigned i = 0; i < n_band; ++i)
+        if (exact[i] < error_min) { error_min = exact[i]; best = (int64_t)i; }
+    if (best >= 0) {
+        *best_index = begin + list[best];
+        *best_cost = error_min;
+        std::memcpy(best_pose, poses.data() + 6 * (size_t)best, 6 * sizeof(double));
+    }
+    if (stats) {
+        stats->n_candidates = n_local;
+        stats->n_rescored = n_band;
+        stats->residuals = (double)n_local * (double)cs.total_pts;
+        stats->kernel_ms = kernel_ms;
+        stats->kernel_launches = n_chunks;
+        stats->total_ms = total_ms;
+    }
+    return CCAL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// least-squares plane
+// ---------------------------------------------------------------------------
+
+static bool solve3(long double A[3][4], long double x[3])
+{
+    for (int c = 0; c < 3; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 3; ++r)
+            if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+        if (A[piv][c] == 0.0L) return false;
+        if (piv != c)
+            for (int k = 0; k < 4; ++k) std::swap(A[c][k], A[piv][k]);
+        for (int r = c + 1; r < 3; ++r) {
+            long double f = A[r][c] / A[c][c];
+            for (int k = c; k < 4; ++k) A[r][k] -= f * A[c][k];
+        }
+    }
+    for (int r = 2; r >= 0; --r) {
+        long double s = A[r][3];
+        for (int k = r + 1; k < 3; ++k) s -= A[r][k] * x[k];
+        x[r] = s / A[r][r];
+    }
+    return true;
+}
+
+extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6],
+                                  float plane_out[4])
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!pose || !plane_out) return fail(ctx, CCAL_ERR_ARG, "fit_plane_lsq: null argument");
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+    std::vector<double> mats((size_t)C * 12);
+    pose_matrices(cs, pose, mats.data());
+    // origin for the moments: the first cloud's centre carried to the base frame
+    double org[3];
+    for (int r = 0; r < 3; ++r)
+        org[r] = mats[r * 4 + 0] * cs.centres[0] + mats[r * 4 + 1] * cs.centres[1] +
+                 mats[r * 4 + 2] * cs.centres[2] + mats[r * 4 + 3];
+    CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
+    CCAL_HIP(ctx, ctx->psum_buf.ensure((size_t)cs.n_blocks * kMoments * sizeof(double)));
+    CCAL_HIP(ctx, ctx->osum_buf.ensure(kMoments * sizeof(double)));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
+                       org[2], ctx->psum_buf.as<double>());
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(kMoments), dim3(64), 0, ctx->stream,
+                       ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
+    CCAL_HIP(ctx, hipGetLastError());
+    double m[kMoments];
+    CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // normal equations of [x y 1](a b c')^T = -z about the origin `org`
+    long double A[3][4] = {{m[4], m[5], m[1], -m[7]},
+                           {m[5], m[6], m[2], -m[8]},
+                           {m[1], m[2], m[0], -m[3]}};
+    long double p[3];
+    if (!solve3(A, p)) return fail(ctx, CCAL_ERR_ARG, "fit_plane_lsq: degenerate point set");
+    const double a = (double)p[0], b = (double)p[1];
+    const double c = (double)(p[2] - p[0] * org[0] - p[1] * org[1] - (long double)org[2]);
+    const double len = std::sqrt(a * a + b * b + 1.0);
+    plane_out[0] = (float)(a / len);
+    plane_out[1] = (float)(b / len);
+    plane_out[2] = (float)(1.0 / len);
+    plane_out[3] = (float)(c / len);
+    return CCAL_OK;
+}

@@ -1,0 +1,90 @@
+// ccal_internal.hpp -- context layout shared by the translation units of libccal.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ccal.h"
+
+namespace ccal {
+
+struct BlockDesc;
+
+// Grow-only device allocation.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        // round up so repeated slightly larger requests do not re-allocate
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct CloudSet {
+    bool ready = false;
+    int n_clouds = 0;
+    std::vector<size_t> n_pts;
+    std::vector<double> base_T_flange;  // n_clouds * 16
+    size_t total_pts = 0;
+
+    // exact path: SoA coordinates of all clouds back to back + block table
+    DevBuf xs, ys, zs, blocks, cloud_block_off_dev, cloud_pt_off_dev;
+    std::vector<int> cloud_block_off;  // n_clouds + 1
+    int n_blocks = 0;
+
+    // fast path: centred 64-point groups
+    DevBuf groups, group_off_dev, scale_dev, centres_dev, base_dev;
+    std::vector<int> group_off;        // n_clouds + 1
+    std::vector<double> centres;       // n_clouds * 3
+    int64_t n_groups = 0;
+    int64_t n_pad_points = 0;          // zero points added to fill the last groups
+    int min_groups = 0;
+
+    void release()
+    {
+        xs.release(); ys.release(); zs.release(); blocks.release();
+        cloud_block_off_dev.release(); cloud_pt_off_dev.release(); groups.release(); group_off_dev.release();
+        scale_dev.release(); centres_dev.release(); base_dev.release();
+        ready = false;
+    }
+};
+
+} // namespace ccal
+
+struct ccal_ctx {
+    int device = -1;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    ccal::CloudSet sets[2];
+    bool plane_set = false;
+    float plane[4] = {0, 0, 0, 0};
+    std::string err;
+
+    // scratch (grow-only)
+    ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
+    ccal::DevBuf mats_buf, planes_buf, psum_buf, pmax_buf, osum_buf, omax_buf, tbl_buf, dist_buf;
+};
+
+namespace ccal {
+
+// Host-side helpers implemented in ccal_api.hip and used by gd.cpp / ransac.
+int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
+               double* cost, double* per_cloud_mean, double* per_cloud_max);
+
+} // namespace ccal

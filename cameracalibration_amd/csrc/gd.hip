@@ -1,0 +1,232 @@
+// gd.hip -- gradient-descent refinement (host loop, batched device passes).
+//
+// Restates the optimiser the reference instantiates at
+// src/camera_calibration_optimization.cpp:428-445 and :486-505:
+//   gdc::GradientDescent<double, Functor, gdc::WolfeBacktracking<double>>
+// with central finite differences (the functor never fills the gradient),
+// momentum 0.4, maxIt 10000, minGradientLength 1e-6, minStepLength 1e-6.
+// gdcpp itself is an unpinned third-party header that is not part of the
+// reference tree; the algorithm below is this library's own statement of it:
+//
+//   loop while it < maxIt and |g| >= minGrad and |step| >= minStep:
+//       x -= step
+//       f, g   = objective and central-difference gradient at x
+//       alpha  = Wolfe backtracking from maxStep (x0.8 per trial) until
+//                f(x-alpha g) <= f - c1 alpha g.g  and  g.g(x-alpha g) <= c2 g.g
+//       step   = momentum*step + (1-momentum)*alpha*g
+//
+// Every stencil (the point itself and +-eps/2 along each axis) is one batched
+// call into the exact objective; several independent descents advance in lock
+// step and share those calls.
+#include "ccal_internal.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Machine {
+    int D = 6;
+    ccal_gd_opts o;
+    double x[10], grad[10], step[10];
+    double fval = 0.0, grad_len = 0.0, step_len = 0.0;
+    int it = 0;
+    int64_t n_evals = 0;
+    // line search
+    double alpha = 0.0, gg = 0.0, xn[10];
+    int ls_it = 0;
+    enum Phase { MAIN, TRIAL, DONE } phase = DONE;
+
+    int stencil() const { return 1 + 2 * D; }
+
+    bool keep_going() const
+    {
+        return (o.max_iterations <= 0 || it < o.max_iterations) &&
+               grad_len >= o.min_gradient_len && step_len >= o.min_step_len;
+    }
+
+    void start(int dim, const double* x0, const ccal_gd_opts& opts)
+    {
+        D = dim;
+        o = opts;
+        std::memset(x, 0, sizeof x);
+        std::memset(grad, 0, sizeof grad);
+        std::memset(step, 0, sizeof step);
+        std::memcpy(x, x0, sizeof(double) * D);
+        grad_len = o.min_gradient_len + 1;
+        step_len = o.min_step_len + 1;
+        it = 0;
+        n_evals = 0;
+        begin_iteration();
+    }
+
+    void begin_iteration()
+    {
+        if (!keep_going()) { phase = DONE; return; }
+        for (int k = 0; k < D; ++k) x[k] -= step[k];
+        phase = MAIN;
+    }
+
+    const double* centre() const { return phase == MAIN ? x : xn; }
+
+    // writes stencil() points of D doubles each
+    void emit(double* out) const
+    {
+        const double* c = centre();
+        std::memcpy(out, c, sizeof(double) * D);
+        for (int i = 0; i < 2 * D; ++i) {
+            double* p = out + (size_t)(1 + i) * D;
+            std::memcpy(p, c, sizeof(double) * D);
+            if (i % 2 == 0) p[i / 2] += o.fd_eps / 2;
+            else            p[i / 2] -= o.fd_eps / 2;
+        }
+    }
+
+    static double dot(const double* a, const double* b, int n)
+    {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i] * b[i];
+        return r;
+    }
+
+    bool trial_allowed() const
+    {
+        return (o.wolfe_max_it <= 0 || ls_it < o.wolfe_max_it) &&
+               alpha * o.wolfe_decrease >= o.wolfe_min_step;
+    }
+
+    void next_trial()
+    {
+        alpha = o.wolfe_decrease * alpha;
+        for (int k = 0; k < D; ++k) xn[k] = x[k] - alpha * grad[k];
+        phase = TRIAL;
+    }
+
+    void finish_iteration()
+    {
+        for (int k = 0; k < D; ++k)
+            step[k] = o.momentum * step[k] + (1 - o.momentum) * alpha * grad[k];
+        step_len = std::sqrt(dot(step, step, D));
+        ++it;
+        begin_iteration();
+    }
+
+    // f holds stencil() objective values in emit() order
+    void feed(const double* f)
+    {
+        n_evals += stencil();
+        double g[10];
+        for (int k = 0; k < D; ++k) g[k] = (f[1 + 2 * k] - f[2 + 2 * k]) / o.fd_eps;
+        if (phase == MAIN) {
+            fval = f[0];
+            std::memcpy(grad, g, sizeof(double) * D);
+            gg = dot(grad, grad, D);
+            grad_len = std::sqrt(gg);
+            alpha = o.wolfe_max_step / o.wolfe_decrease;
+            ls_it = 0;
+            if (trial_allowed()) next_trial();
+            else finish_iteration();
+        } else if (phase == TRIAL) {
+            const bool armijo = f[0] <= fval - o.wolfe_c1 * alpha * gg;
+            const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
+            ++ls_it;
+            if (!(armijo && wolfe) && trial_allowed()) next_trial();
+            else finish_iteration();
+        }
+    }
+
+    void result(ccal_gd_result* r) const
+    {
+        r->iterations = it;
+        r->converged = grad_len < o.min_gradient_len || step_len < o.min_step_len;
+        r->fval = fval;
+        std::memset(r->xval, 0, sizeof r->xval);
+        std::memcpy(r->xval, x, sizeof(double) * D);
+        r->n_evals = n_evals;
+    }
+};
+
+} // namespace
+
+extern "C" void ccal_gd_default_opts(ccal_gd_opts* o)
+{
+    if (!o) return;
+    o->max_iterations = 10000;
+    o->min_gradient_len = 1e-6;
+    o->min_step_len = 1e-6;
+    o->momentum = 0.4;
+    o->fd_eps = std::sqrt(DBL_EPSILON);
+    o->wolfe_decrease = 0.8;
+    o->wolfe_c1 = 1e-4;
+    o->wolfe_c2 = 0.9;
+    o->wolfe_min_step = 1e-10;
+    o->wolfe_max_step = 1.0;
+    o->wolfe_max_it = 0;
+}
+
+extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_starts,
+                                      const double* x0, const ccal_gd_opts* opts,
+                                      ccal_gd_result* results)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if ((dim != 6 && dim != 10) || n_starts <= 0 || !x0 || !results) {
+        ctx->err = "gd_minimize: dim must be 6 or 10 and arguments non-null";
+        return CCAL_ERR_ARG;
+    }
+    if (which != CCAL_DOWNSAMPLED && which != CCAL_RAW) {
+        ctx->err = "cloud-set selector must be CCAL_DOWNSAMPLED or CCAL_RAW";
+        return CCAL_ERR_ARG;
+    }
+    if (!ctx->sets[which].ready) { ctx->err = "cloud set not uploaded"; return CCAL_ERR_STATE; }
+    if (dim == 6 && !ctx->plane_set) { ctx->err = "gd_minimize: plane not set"; return CCAL_ERR_STATE; }
+    ccal_gd_opts o;
+    if (opts) o = *opts;
+    else ccal_gd_default_opts(&o);
+    if (!(o.fd_eps > 0) || !(o.wolfe_decrease > 0 && o.wolfe_decrease < 1)) {
+        ctx->err = "gd_minimize: fd_eps must be > 0 and wolfe_decrease in (0,1)";
+        return CCAL_ERR_ARG;
+    }
+
+    std::vector<Machine> ms(n_starts);
+    for (int s = 0; s < n_starts; ++s) ms[s].start(dim, x0 + (size_t)s * dim, o);
+
+    const int S = 1 + 2 * dim;
+    std::vector<double> pts, poses, planes, f;
+    std::vector<int> active;
+    for (;;) {
+        active.clear();
+        for (int s = 0; s < n_starts; ++s)
+            if (ms[s].phase != Machine::DONE) active.push_back(s);
+        if (active.empty()) break;
+        const size_t n = active.size() * (size_t)S;
+        pts.resize(n * dim);
+        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].emit(pts.data() + a * S * dim);
+        poses.resize(n * 6);
+        f.resize(n);
+        const double* planes_ptr = nullptr;
+        if (dim == 10) {
+            planes.resize(n * 4);
+            for (size_t i = 0; i < n; ++i) {
+                std::memcpy(&poses[i * 6], &pts[i * 10], 6 * sizeof(double));
+                std::memcpy(&planes[i * 4], &pts[i * 10 + 6], 4 * sizeof(double));
+            }
+            planes_ptr = planes.data();
+        } else {
+            std::memcpy(poses.data(), pts.data(), n * 6 * sizeof(double));
+        }
+        int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), planes_ptr, f.data(), nullptr,
+                                  nullptr);
+        if (rc != CCAL_OK) return rc;
+        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + a * S);
+    }
+    for (int s = 0; s < n_starts; ++s) ms[s].result(&results[s]);
+    return CCAL_OK;
+}
+
+extern "C" int ccal_gd_minimize(ccal_ctx* ctx, int which, int dim, const double* x0,
+                                const ccal_gd_opts* opts, ccal_gd_result* result)
+{
+    return ccal_gd_minimize_multi(ctx, which, dim, 1, x0, opts, result);
+}

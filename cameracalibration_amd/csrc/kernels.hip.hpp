@@ -1,0 +1,605 @@
+// kernels.hip.hpp -- gfx950 kernels of the calibration hot path.
+//
+// Two arithmetic families:
+//   * "fast": FP32, the point-to-plane residual folded into a 4-vector per
+//     (candidate, cloud) and contracted with homogeneous points on the matrix
+//     cores: v_mfma_f32_16x16x4_f32 is exactly a K=4 contraction of a
+//     16-candidate tile with a 16-point tile, bit-identical to an fmaf chain.
+//     |.| and the running sum are VALU adds on the MFMA result.
+//   * "exact": the reference's own arithmetic (FP64 SE3 apply in the SSE2
+//     summation order, point rounded to float, FP64 distance with a true
+//     division, distances of a cloud added one by one in point order), used for
+//     single poses, finite-difference stencils, the error report and for
+//     re-scoring near-minimum grid candidates.  Its results are bit-identical
+//     to the CPU evaluation of the same lines.
+//
+// Included once by ccal_api.hip; everything here is internal.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pose_math.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ccal {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Layouts
+// ---------------------------------------------------------------------------
+// Fast path points: "groups" of 64 points = 4 MFMA tiles of 16 points.  A group
+// is 64 lanes x float4 (1 KiB), so one global_load_dwordx4 per lane fetches the
+// four B operands of a wave: component u of lane l is element l of tile u,
+// element l = k*16 + col holds coordinate k (x,y,z,one) of point u*16 + col.
+// Points are stored relative to their cloud's centre; padding points are all
+// zero including `one`, so they contribute |0| to every sum.
+//
+// Fast path candidates: W[cloud][ctile][k*16 + cand] (64 floats per tile), one
+// coalesced dword per lane is the A operand of a 16-candidate tile.
+constexpr int kGroupPoints = 64;
+constexpr int kTilePoints = 16;
+constexpr int kFlushGroups = 32;  // FP32 partial sums are promoted every 128 adds
+
+// ---------------------------------------------------------------------------
+// Candidate sources for the W generator
+// ---------------------------------------------------------------------------
+// Grid: per axis a table of translations (axes 0..2) or of sin/cos pairs
+// (axes 3..5), built on the host in FP64 with the reference's formulas.
+struct GridTables {
+    const double* t[3];    // t[k][i] = base[k] + value/1000.0
+    const double* sn[3];   // sn[k][i] = sin(base[3+k] + value*3.141592/180)
+    const double* cs[3];
+    int count[6];
+    int64_t first;         // linear index of chunk candidate 0
+};
+
+// List: explicit records of 9 doubles: t[3], sin[3], cos[3].
+struct PoseList {
+    const double* rec;
+};
+
+struct FoldConsts {
+    double n[3];
+    double d;
+    double inv_norm;
+};
+
+__device__ inline void fetch_pose(const GridTables& g, int64_t c, double t[3], double s[3],
+                                  double cs[3])
+{
+    int64_t idx = g.first + c;
+    int i5 = (int)(idx % g.count[5]); idx /= g.count[5];
+    int i4 = (int)(idx % g.count[4]); idx /= g.count[4];
+    int i3 = (int)(idx % g.count[3]); idx /= g.count[3];
+    int i2 = (int)(idx % g.count[2]); idx /= g.count[2];
+    int i1 = (int)(idx % g.count[1]); idx /= g.count[1];
+    int i0 = (int)idx;
+    t[0] = g.t[0][i0]; t[1] = g.t[1][i1]; t[2] = g.t[2][i2];
+    s[0] = g.sn[0][i3]; s[1] = g.sn[1][i4]; s[2] = g.sn[2][i5];
+    cs[0] = g.cs[0][i3]; cs[1] = g.cs[1][i4]; cs[2] = g.cs[2][i5];
+}
+
+__device__ inline void fetch_pose(const PoseList& p, int64_t c, double t[3], double s[3],
+                                  double cs[3])
+{
+    const double* r = p.rec + c * 9;
+    for (int k = 0; k < 3; ++k) { t[k] = r[k]; s[k] = r[3 + k]; cs[k] = r[6 + k]; }
+}
+
+// One thread per candidate; loops over clouds.  Candidates >= n_valid (padding
+// up to the launch tile) get w = 0.
+template <typename Source>
+__global__ __launch_bounds__(256) void wgen_kernel(Source src, int64_t n_valid, int n_ctiles,
+                                                    int n_clouds,
+                                                    const double* __restrict__ base_T_flange,
+                                                    const double* __restrict__ centres,
+                                                    FoldConsts fc, float* __restrict__ W)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)n_ctiles * kTilePoints) return;
+    const bool valid = c < n_valid;
+    double R[9], t[3] = {0, 0, 0};
+    if (valid) {
+        double s[3], cs[3];
+        fetch_pose(src, c, t, s, cs);
+        rotation_zyx(s, cs, R);
+    }
+    const int64_t tile = c >> 4;
+    const int col = (int)(c & 15);
+    for (int j = 0; j < n_clouds; ++j) {
+        double w[4] = {0, 0, 0, 0};
+        if (valid) {
+            double M[12];
+            compose_rows(base_T_flange + 16 * j, R, t, M);
+            fold_plane(M, fc.n, fc.d, fc.inv_norm, centres + 3 * j, w);
+        }
+        float* dst = W + ((int64_t)j * n_ctiles + tile) * 64 + col;
+        dst[0] = (float)w[0];
+        dst[16] = (float)w[1];
+        dst[32] = (float)w[2];
+        dst[48] = (float)w[3];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fast residual kernel
+// ---------------------------------------------------------------------------
+// grid = (candidate blocks, point splits); block = 4 waves; wave w of block bx
+// owns candidate tiles [(bx*4+w)*NA, +NA).  All four waves stream the same
+// point groups (their loads coalesce in L1/L2), split `by` of every cloud.
+// Output: partial[by][candidate] = sum_j scale_j * sum_{i in split} |w.p|.
+template <int NA>
+__global__ __launch_bounds__(256) void residual_mfma_kernel(
+    const float* __restrict__ W, const f32x4* __restrict__ groups,
+    const int* __restrict__ group_off, const double* __restrict__ scale,
+    double* __restrict__ partial, int n_clouds, int n_ctiles, int n_splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ctile0 = (blockIdx.x * 4 + wave) * NA;
+    const int split = blockIdx.y;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    double accD[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accD[a][r] = 0.0;
+
+    for (int j = 0; j < n_clouds; ++j) {
+        const int g0 = group_off[j];
+        const int G = group_off[j + 1] - g0;
+        const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
+        const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
+        if (gb >= ge) continue;
+        float A[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+            A[a] = W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane];
+        const double sc = scale[j];
+
+        float acc[NA][4];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+
+        const f32x4* gp = groups + (int64_t)gb * 64 + lane;
+        f32x4 b = gp[0];
+        // Retire the A and first-B loads here, so that inside the loop the only
+        // outstanding load is the next group's prefetch (vmcnt(0), others max).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        int since = 0;
+        // Two-deep software pipeline: the |d| adds of MFMA k are issued after
+        // MFMAs k+1 and k+2, which covers the matrix pipe's result latency
+        // without idle slots.  The last two results of a group are carried into
+        // the next iteration (they start as zero, and |0| adds nothing).
+        f32x4 carry0 = zero, carry1 = zero;
+        for (int g = gb; g < ge; ++g) {
+            // register double buffer: fetch the next group before using this one
+            f32x4 bn = b;
+            if (g + 1 < ge) bn = gp[64];
+            gp += 64;
+            f32x4 d[4 * NA];
+#pragma unroll
+            for (int idx = 0; idx < 4 * NA; ++idx) {
+                d[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[idx % NA], b[idx / NA], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                const f32x4 done = idx == 0 ? carry0 : (idx == 1 ? carry1 : d[idx >= 2 ? idx - 2 : 0]);
+                const int a = (idx + 4 * NA - 2) % NA;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][r] += __builtin_fabsf(done[r]);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            carry0 = d[4 * NA - 2];
+            carry1 = d[4 * NA - 1];
+            b = bn;
+            if (++since == kFlushGroups) {
+                since = 0;
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accD[a][r] += (double)acc[a][r] * sc;
+                        acc[a][r] = 0.f;
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[NA - 2][r] += __builtin_fabsf(carry0[r]);
+            acc[NA - 1][r] += __builtin_fabsf(carry1[r]);
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accD[a][r] += (double)acc[a][r] * sc;
+    }
+
+    // D layout: lane l, register r holds candidate row (l>>4)*4 + r and point
+    // column l&15, so the 16 lanes of a DPP row share their four candidates.
+    double* out = partial + (int64_t)split * n_ctiles * 16;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double v = accD[a][r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if ((lane & 15) == 0)
+                out[(int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r] = v;
+        }
+}
+
+// Same contraction, counting |w.p| < thr instead of summing (RANSAC scoring).
+// Padding points have residual 0 and are counted; the host subtracts them.
+template <int NA>
+__global__ __launch_bounds__(256) void inlier_mfma_kernel(
+    const float* __restrict__ W, const f32x4* __restrict__ groups,
+    const int* __restrict__ group_off, unsigned long long* __restrict__ partial,
+    float thr, int n_clouds, int n_ctiles, int n_splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ctile0 = (blockIdx.x * 4 + wave) * NA;
+    const int split = blockIdx.y;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    unsigned int cnt[NA][4];
+    unsigned long long tot[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cnt[a][r] = 0; tot[a][r] = 0; }
+
+    for (int j = 0; j < n_clouds; ++j) {
+        const int g0 = group_off[j];
+        const int G = group_off[j + 1] - g0;
+        const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
+        const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
+        if (gb >= ge) continue;
+        float A[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+            A[a] = W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane];
+        const f32x4* gp = groups + (int64_t)gb * 64 + lane;
+        f32x4 b = gp[0];
+        for (int g = gb; g < ge; ++g) {
+            f32x4 bn = b;
+            if (g + 1 < ge) bn = gp[64];
+            gp += 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a], b[u], zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cnt[a][r] += (__builtin_fabsf(d[r]) < thr) ? 1u : 0u;
+                }
+            }
+            b = bn;
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tot[a][r] += cnt[a][r]; cnt[a][r] = 0; }
+    }
+    unsigned long long* out = partial + (int64_t)split * n_ctiles * 16;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned long long v = tot[a][r];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if ((lane & 15) == 0)
+                out[(int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r] = v;
+        }
+}
+
+// cost[c] = sum over splits (fixed order, deterministic)
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __restrict__ partial,
+                                                            int64_t n_padded, int n_splits,
+                                                            int64_t n_valid,
+                                                            float* __restrict__ cost)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_valid) return;
+    double s = 0.0;
+    for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * n_padded + c];
+    cost[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void reduce_splits_u64_kernel(
+    const unsigned long long* __restrict__ partial, int64_t n_padded, int n_splits,
+    int64_t n_valid, unsigned long long* __restrict__ count)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_valid) return;
+    unsigned long long s = 0;
+    for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * n_padded + c];
+    count[c] = s;
+}
+
+// ---------------------------------------------------------------------------
+// arg-min over a cost array: lowest cost, lowest index on ties
+// ---------------------------------------------------------------------------
+struct MinRec {
+    float cost;
+    int pad;
+    int64_t index;
+};
+
+__device__ inline bool rec_less(float ca, int64_t ia, float cb, int64_t ib)
+{
+    return ca < cb || (ca == cb && ia < ib);
+}
+
+__device__ inline void block_min(float& c, int64_t& i, float* sc, int64_t* si)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        float oc = __shfl_xor(c, off, 64);
+        int64_t oi = __shfl_xor(i, off, 64);
+        if (rec_less(oc, oi, c, i)) { c = oc; i = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sc[wave] = c; si[wave] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (rec_less(sc[w], si[w], c, i)) { c = sc[w]; i = si[w]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void argmin_stage1_kernel(const float* __restrict__ cost,
+                                                            int64_t n, MinRec* __restrict__ out)
+{
+    __shared__ float sc[4];
+    __shared__ int64_t si[4];
+    float c = __builtin_inff();
+    int64_t i = INT64_MAX;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        float v = cost[k];
+        if (rec_less(v, k, c, i)) { c = v; i = k; }
+    }
+    block_min(c, i, sc, si);
+    if (threadIdx.x == 0) { out[blockIdx.x].cost = c; out[blockIdx.x].index = i; }
+}
+
+__global__ __launch_bounds__(256) void argmin_stage2_kernel(const MinRec* __restrict__ in, int n,
+                                                            MinRec* __restrict__ out)
+{
+    __shared__ float sc[4];
+    __shared__ int64_t si[4];
+    float c = __builtin_inff();
+    int64_t i = INT64_MAX;
+    for (int k = threadIdx.x; k < n; k += blockDim.x)
+        if (rec_less(in[k].cost, in[k].index, c, i)) { c = in[k].cost; i = in[k].index; }
+    block_min(c, i, sc, si);
+    if (threadIdx.x == 0) { out->cost = c; out->index = i; }
+}
+
+// Appends every candidate with cost <= min*(1+band) to `list` (order arbitrary;
+// the host sorts).  count may exceed cap: entries past cap are dropped and the
+// host reports the overflow.
+__global__ __launch_bounds__(256) void select_band_kernel(const float* __restrict__ cost,
+                                                          int64_t n, const MinRec* __restrict__ mn,
+                                                          float band, int64_t* __restrict__ list,
+                                                          unsigned int cap,
+                                                          unsigned int* __restrict__ count)
+{
+    const float limit = mn->cost * (1.0f + band);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        if (cost[k] <= limit) {
+            unsigned int slot = atomicAdd(count, 1u);
+            if (slot < cap) list[slot] = k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact path
+// ---------------------------------------------------------------------------
+// A block covers a contiguous run of points of one cloud.
+struct BlockDesc {
+    int cloud;
+    int first_of_cloud;  // index of the cloud's first block (for the finaliser)
+    int64_t begin;
+    int64_t end;
+};
+
+// Per (pose, cloud): rows 0..2 of M = base_T_flange_j * F(pose), 12 doubles.
+// Per pose: plane a,b,c,d and sqrt(a^2+b^2+c^2), 5 doubles (padded to 8).
+constexpr int kPlaneStride = 8;
+
+__device__ inline double exact_distance(const double* M, const double* pl, float x, float y,
+                                        float z)
+{
+    // src/helpers.hpp:139-151: p = col3; p = v_i*col_i + p (i = 0,1,2); -> float
+    const double xd = (double)x, yd = (double)y, zd = (double)z;
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double p = M[r * 4 + 3];
+        p = xd * M[r * 4 + 0] + p;
+        p = yd * M[r * 4 + 1] + p;
+        p = zd * M[r * 4 + 2] + p;
+        q[r] = (float)p;
+    }
+    // src/camera_calibration_optimization.cpp:121-129
+    const double num = pl[0] * (double)q[0] + pl[1] * (double)q[1] + pl[2] * (double)q[2] + pl[3];
+    return __builtin_fabs(num) / pl[4];
+}
+
+// Distances of every point for PB poses: dist[k][i] (pose-major, i = global point
+// index) plus the per-block maximum.  The sums are NOT formed here: the
+// reference adds the distances of a cloud one by one in point order
+// (src/camera_calibration_optimization.cpp:305), and floating-point addition is
+// not associative, so the ordered sum is a separate single-chain pass below.
+template <int PB>
+__global__ __launch_bounds__(256) void exact_dist_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
+    const double* __restrict__ planes, int n_clouds, int64_t total_pts,
+    double* __restrict__ dist, double* __restrict__ part_max)
+{
+    __shared__ double sM[PB * 12];
+    __shared__ double sP[PB * kPlaneStride];
+    __shared__ double red_m[4][PB];
+    const BlockDesc bd = blocks[blockIdx.x];
+    for (int i = threadIdx.x; i < PB * 12; i += blockDim.x) {
+        int k = i / 12, e = i % 12;
+        sM[i] = mats[((int64_t)k * n_clouds + bd.cloud) * 12 + e];
+    }
+    for (int i = threadIdx.x; i < PB * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
+    __syncthreads();
+
+    double mx[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) mx[k] = -1e9;  // :288 error_mx = -1e9
+
+    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+#pragma unroll
+        for (int k = 0; k < PB; ++k) {
+            const double d = exact_distance(sM + k * 12, sP + k * kPlaneStride, x, y, z);
+            dist[(int64_t)k * total_pts + i] = d;
+            if (d > mx[k]) mx[k] = d;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+        double m = mx[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            double om = __shfl_xor(m, off, 64);
+            m = om > m ? om : m;
+        }
+        if (lane == 0) red_m[wave][k] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < PB) {
+        const int k = threadIdx.x;
+        double m = red_m[0][k];
+        for (int w = 1; w < 4; ++w) m = red_m[w][k] > m ? red_m[w][k] : m;
+        part_max[(int64_t)blockIdx.x * PB + k] = m;
+    }
+}
+
+// One lane per (pose k, cloud j) chain: average = ((0 + d_0) + d_1) + ... in
+// point order, exactly the reference's accumulation.  64 chains advance per
+// wave instruction; each lane streams its own row of `dist`.
+__global__ __launch_bounds__(64) void ordered_sum_kernel(const double* __restrict__ dist,
+                                                         const int64_t* __restrict__ cloud_pt_off,
+                                                         int n_chains, int n_clouds,
+                                                         int64_t total_pts,
+                                                         double* __restrict__ out_sum)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_chains) return;
+    const int k = c / n_clouds, j = c % n_clouds;
+    const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
+    const double* row = dist + (int64_t)k * total_pts;
+    double s = 0.0;
+    int64_t i = b;
+    for (; i + 8 <= e; i += 8) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = row[i + t];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += v[t];
+    }
+    for (; i < e; ++i) s += row[i];
+    out_sum[c] = s;
+}
+
+// One wave per (pose k, cloud j): maximum over the cloud's block maxima.
+__global__ __launch_bounds__(64) void exact_max_kernel(const double* __restrict__ part_max,
+                                                       const int* __restrict__ cloud_block_off,
+                                                       int PB, int n_clouds,
+                                                       double* __restrict__ out_max)
+{
+    const int k = blockIdx.x / n_clouds, j = blockIdx.x % n_clouds;
+    const int b0 = cloud_block_off[j], b1 = cloud_block_off[j + 1];
+    double m = -1e9;
+    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
+        double v = part_max[(int64_t)b * PB + k];
+        m = v > m ? v : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        double om = __shfl_xor(m, off, 64);
+        m = om > m ? om : m;
+    }
+    if (threadIdx.x == 0) out_max[k * n_clouds + j] = m;
+}
+
+// Moments of the base-frame points q = float(M p) for the z-regression plane fit
+// (src/camera_calibration_optimization.cpp:100-119 on the cloud of :240-272).
+// Accumulated about a fixed origin `org` (the host passes an approximate
+// centroid) so the normal equations stay well conditioned in FP64.
+// Order of the 9 sums: 1, x, y, z, xx, xy, yy, xz, yz.
+constexpr int kMoments = 9;
+
+__global__ __launch_bounds__(256) void moments_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats, double ox, double oy,
+    double oz, double* __restrict__ part)
+{
+    __shared__ double sM[12];
+    __shared__ double red[4][kMoments];
+    const BlockDesc bd = blocks[blockIdx.x];
+    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+    __syncthreads();
+    double m[kMoments];
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) m[k] = 0.0;
+    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+        const double xd = (double)xs[i], yd = (double)ys[i], zd = (double)zs[i];
+        float q[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double p = sM[r * 4 + 3];
+            p = xd * sM[r * 4 + 0] + p;
+            p = yd * sM[r * 4 + 1] + p;
+            p = zd * sM[r * 4 + 2] + p;
+            q[r] = (float)p;
+        }
+        const double x = (double)q[0] - ox, y = (double)q[1] - oy, z = (double)q[2] - oz;
+        m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+        m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+        double s = m[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        const int k = threadIdx.x;
+        part[(int64_t)blockIdx.x * kMoments + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+}
+
+__global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ part,
+                                                              int n_blocks,
+                                                              double* __restrict__ out)
+{
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) s += part[(int64_t)b * kMoments + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) out[k] = s;
+}
+
+} // namespace ccal

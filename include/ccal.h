@@ -1,0 +1,192 @@
+/*
+ * ccal.h -- C ABI of the MI355X hand-eye plane-calibration hot path.
+ *
+ * The reference (REXJJ/CameraCalibration) has no plugin or FFI layer: its hot
+ * path is a set of C++ member functions on one global `Optimizer` object.  Each
+ * entry point below replaces one of those call seams; the comment above it
+ * names the reference lines it stands in for (paths relative to the reference
+ * tree).  A host program written against the reference binds these instead of
+ * the member functions; see INTEGRATION.md for the call-site patch.
+ *
+ * Conventions
+ *   - every function returns an int status: CCAL_OK (0) or a negative code;
+ *     no exception crosses the boundary; ccal_last_error() gives the text.
+ *   - a context is bound to ONE GPU and used from one host thread at a time;
+ *     run one context per GPU (one process per GPU, or one host thread each).
+ *   - host pointers are borrowed only for the duration of a call.
+ *   - poses are 6 doubles (tx,ty,tz [m], rz,ry,rx [rad]) as in the reference's
+ *     `flange_transformation`; matrices are 4x4 row-major doubles.
+ *   - the library never falls back to a CPU path: without a usable GPU every
+ *     compute entry point fails with CCAL_ERR_DEVICE.
+ */
+#ifndef CCAL_H
+#define CCAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    CCAL_OK            =  0,
+    CCAL_ERR_ARG       = -1,  /* bad argument (null pointer, bad size/selector) */
+    CCAL_ERR_DEVICE    = -2,  /* HIP error or no device */
+    CCAL_ERR_STATE     = -3,  /* clouds / plane not set yet */
+    CCAL_ERR_CAPACITY  = -4,  /* a bounded internal list overflowed */
+    CCAL_ERR_IO        = -5   /* file could not be read / unsupported format */
+};
+
+/* which cloud set an operation uses: the reference keeps two per run,
+ * `cloud_downsampled` (objective, camera_calibration_optimization.cpp:295) and
+ * `clouds` (raw; plane fit :240-273 and the error report :389-404). */
+enum { CCAL_DOWNSAMPLED = 0, CCAL_RAW = 1 };
+
+typedef struct ccal_ctx ccal_ctx;
+
+/* Library / context lifetime.  Replaces the global `Optimizer opti`
+ * (camera_calibration_optimization.cpp:409). */
+int  ccal_create(int device_id, ccal_ctx** out);
+int  ccal_destroy(ccal_ctx* ctx);
+const char* ccal_last_error(const ccal_ctx* ctx);
+const char* ccal_status_string(int status);
+/* Number of GPUs visible to the process (0 when there is none). */
+int  ccal_device_count(void);
+
+/* One-time device-resident upload of a cloud set.  Replaces the members
+ * `clouds` / `cloud_downsampled` / `inverse_kinematics` / `mapping`
+ * (camera_calibration_optimization.cpp:48-60, filled at :158-210).
+ *   xyz[j]        n_pts[j] points, AoS float x,y,z (stride 3)
+ *   base_T_flange n_clouds 4x4 matrices, ALREADY mapped: entry j is
+ *                 inverse_kinematics[mapping[j]] (:290)
+ * Empty clouds (n_pts[j]==0) are rejected: the reference divides by the count. */
+int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
+                       const float* const* xyz, const size_t* n_pts,
+                       const double* base_T_flange);
+
+/* The reference plane `Optimizer::plane` (Eigen::Vector4f, :53, set at :274). */
+int ccal_set_plane(ccal_ctx* ctx, const float plane[4]);
+int ccal_get_plane(const ccal_ctx* ctx, float plane[4]);
+
+/* Objective, reference arithmetic (FP64 transform, point rounded to float, FP64
+ * distance).  Replaces
+ *   double Optimizer::getError(vector<double>)                  :280-313
+ *   double Optimizer::getError(vector<double>, vector<double>)  :314-347
+ *   the per-cloud mean/max of Optimizer::printError             :348-407
+ * for a batch of poses in one pass over the points.
+ *   poses6   n_poses*6
+ *   planes4  NULL -> every pose uses the context plane (float, as :121);
+ *            else n_poses*4 doubles, one caller plane per pose (as :126)
+ *   cost     n_poses        mean over clouds of per-cloud mean distance [m]
+ *   per_cloud_mean/max      NULL or n_poses*n_clouds                    [m] */
+int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+              const double* planes4, double* cost,
+              double* per_cloud_mean, double* per_cloud_max);
+
+/* Same objective for a large batch of poses on the fast FP32 path (folded
+ * 4-vector, matrix-core K=4 contraction).  Costs agree with ccal_eval to
+ * ~1e-6 relative; used where thousands..millions of poses are scored.
+ * Uses the context plane. */
+int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* poses6,
+                   float* cost);
+
+/* Candidate grid of discreteCombinatorialOptimization (:526-558), generalised:
+ * axis k perturbs pose[k]; axes 0..2 in millimetres, 3..5 in degrees
+ * (rad = deg*3.141592/180 as helpers.hpp:275-278); value_i = min + i*step;
+ * linear candidate index is row-major with axis 5 fastest, which is the
+ * reference's loop-nest order x,y,z,zt,yt,xt. */
+typedef struct {
+    double min[6];
+    double step[6];
+    int    count[6];
+} ccal_grid;
+
+/* The shipped 11^6 grid: +-20 mm step 4, +-5 deg step 1 (:532-538). */
+void ccal_grid_default(ccal_grid* g);
+int64_t ccal_grid_size(const ccal_grid* g);
+void ccal_grid_pose(const ccal_grid* g, const double base_pose[6], int64_t index,
+                    double pose[6]);
+
+typedef struct {
+    int64_t n_candidates;   /* scored by this call */
+    int64_t n_rescored;     /* near-minimum candidates re-scored with ccal_eval arithmetic */
+    double  residuals;      /* candidate x point evaluations on the fast path */
+    double  kernel_ms;      /* HIP-event time of the residual kernels, summed */
+    int     kernel_launches;
+    double  total_ms;       /* HIP-event time of the whole call's device work */
+} ccal_grid_stats;
+
+/* Arg-min of the objective over grid candidates [begin,end) on this GPU.
+ * Replaces the 6-deep loop nest :533-548.  The winner is the lowest-index
+ * minimum of the reference-arithmetic cost (strict '<', :542): every candidate
+ * whose fast-path cost is within a relative band of the fast-path minimum is
+ * re-scored with ccal_eval arithmetic before the final comparison.
+ * Shards of one grid (one per GPU) are merged with ccal_argmin_merge or an
+ * all-gather of (cost,index) pairs.  stats may be NULL. */
+int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
+                     const ccal_grid* g, int64_t begin, int64_t end,
+                     int64_t* best_index, double* best_cost, double best_pose[6],
+                     ccal_grid_stats* stats);
+
+/* Lexicographic (cost, index) minimum over n shard results; entries with
+ * index < 0 (empty shards) are skipped.  Returns the winning slot or -1. */
+int ccal_argmin_merge(int n, const double* costs, const int64_t* indices);
+
+/* Least-squares plane of every point of the set carried to the base frame by
+ * `pose`.  Replaces fitPlane (:100-119) applied to the cloud assembled at
+ * :240-272: solves a*x + b*y + c = -z, returns (a,b,1,c)/|(a,b,1)| as floats. */
+int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6], float plane_out[4]);
+
+/* RANSAC plane with the parameters of getPlane (cloud_analyzer.cpp:103-121:
+ * SACMODEL_PLANE, SAC_RANSAC, distance threshold, optimise coefficients):
+ * n_hyp three-point hypotheses drawn with a counter-based generator from
+ * `seed`, every hypothesis scored against every point of the set in one batched
+ * pass, best hypothesis refitted on its inliers (total least squares).
+ * plane_out is (n, d) with |n| = 1 and n.z >= 0. */
+int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6], int n_hyp,
+                      float threshold, uint64_t seed, float plane_out[4],
+                      int64_t* inliers_out);
+
+/* Gradient-descent refinement with the reference's gdcpp settings.  Replaces
+ * gradientDescent (:411-465) for dim 6 and gradientDescentWithPlane (:466-524)
+ * for dim 10 (x = pose ++ plane).  Every objective value is ccal_eval
+ * arithmetic; each finite-difference stencil is one batched device pass. */
+typedef struct {
+    int    max_iterations;   /* 10000  (:431) */
+    double min_gradient_len; /* 1e-6   (:432) */
+    double min_step_len;     /* 1e-6   (:433) */
+    double momentum;         /* 0.4    (:434) */
+    double fd_eps;           /* central-difference step, sqrt(DBL_EPSILON) */
+    double wolfe_decrease;   /* 0.8 */
+    double wolfe_c1;         /* 1e-4 */
+    double wolfe_c2;         /* 0.9 */
+    double wolfe_min_step;   /* 1e-10 */
+    double wolfe_max_step;   /* 1.0 */
+    int    wolfe_max_it;     /* 0 = unlimited */
+} ccal_gd_opts;
+
+typedef struct {
+    int     iterations;
+    int     converged;
+    double  fval;
+    double  xval[10];
+    int64_t n_evals;         /* objective evaluations (poses scored) */
+} ccal_gd_result;
+
+void ccal_gd_default_opts(ccal_gd_opts* o);
+int  ccal_gd_minimize(ccal_ctx* ctx, int which, int dim, const double* x0,
+                      const ccal_gd_opts* opts, ccal_gd_result* result);
+/* n_starts independent descents advanced in lock step, their stencils batched
+ * into shared device passes.  x0 is n_starts*dim, results has n_starts slots. */
+int  ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_starts,
+                            const double* x0, const ccal_gd_opts* opts,
+                            ccal_gd_result* results);
+
+/* Pose math shared with callers (helpers.cpp:45-71): ZYX pose -> 4x4. */
+void ccal_pose_to_matrix(const double pose[6], double T[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCAL_H */

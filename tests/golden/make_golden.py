@@ -1,0 +1,101 @@
+"""Regenerates tests/golden/*.npz / *.json.
+
+The reference ships no golden vectors, expected outputs or tests (its only
+"validation" is visual), so these fixtures pin the CPU oracle, not the
+reference: inputs are data files of the reference (example/calib_1) reduced to a
+size that can be committed, expected outputs are what oracle/ccal_oracle.c
+computes from them.  Parity status of everything here: "parity unpinned".
+
+Run from the repo root in the build container (needs /root/reference):
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from cameracalibration_amd.synthetic import make_scene  # noqa: E402
+
+REF = "/root/reference/example/calib_1/"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def read_ply_xyz(path):
+    f = open(path, "rb").read()
+    h = f.index(b"end_header\n") + 11
+    n = int([l for l in f[:h].split(b"\n") if l.startswith(b"element vertex")][0].split()[-1])
+    return np.frombuffer(f[h:h + 12 * n], dtype="<f4").reshape(n, 3).copy()
+
+
+def main():
+    clouds = []
+    for i in range(1, 5):
+        a = read_ply_xyz(REF + "pointcloud/cloud_%d.ply" % i)
+        clouds.append(a[a[:, 2] <= 0.8])
+    ik_lines = [l for l in open(REF + "BaseToFlange.csv").read().split("\n") if l.strip()]
+    B = np.stack([O.pose_to_matrix(O.parse_pose_csv(l)) for l in ik_lines])
+    pose = O.parse_pose_csv("0.0204504,0.111258,0.0505291,-3.15376,-0.0280023,1.58043")
+
+    raw = O.OracleScene(clouds, B)
+    plane_full = O.fit_plane(raw.combined_cloud(pose))
+    ds = [O.voxel_grid(c) for c in clouds]
+    sub = [c[::32].copy() for c in clouds]          # committed stand-in for the raw clouds
+    sc = O.OracleScene(ds, B)
+    ssub = O.OracleScene(sub, B)
+    plane_sub = O.fit_plane(ssub.combined_cloud(pose))
+
+    mean, mx = sc.per_cloud_error(pose, plane_full)
+    mean_s, mx_s = ssub.per_cloud_error(pose, plane_full)
+    g = O.grid_default()
+    first = 4096
+    _, _, _, costs = sc.grid_search(plane_full, pose, g, 0, first, want_costs=True)
+    g5 = O.make_grid([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6)
+    bi, bc, bp, _ = sc.grid_search(plane_full, pose, g5)
+    gd6 = sc.gd_minimize(plane_full, pose)
+    x10 = np.concatenate([np.array(gd6.xval[:6]), plane_full.astype(np.float64)])
+    gd10 = sc.gd_minimize(plane_full, x10)
+
+    np.savez_compressed(
+        os.path.join(OUT, "calib1.npz"),
+        ds_0=ds[0], ds_1=ds[1], ds_2=ds[2], ds_3=ds[3],
+        sub_0=sub[0], sub_1=sub[1], sub_2=sub[2], sub_3=sub[3],
+        base_T_flange=B, pose_init=pose, plane_full=plane_full, plane_sub=plane_sub,
+        ds_mean=mean, ds_max=mx, sub_mean=mean_s, sub_max=mx_s,
+        cost_init=np.array(sc.get_error(pose, plane_full)),
+        grid_first_costs=costs,
+        grid5_best=np.array([bi]), grid5_cost=np.array([bc]), grid5_pose=bp,
+        gd6_x=np.array(gd6.xval[:6]), gd6_f=np.array([gd6.fval]),
+        gd6_it=np.array([gd6.iterations, gd6.converged, gd6.n_evals]),
+        gd10_x=np.array(gd10.xval[:10]), gd10_f=np.array([gd10.fval]),
+        gd10_it=np.array([gd10.iterations, gd10.converged, gd10.n_evals]),
+        n_raw=np.array([c.shape[0] for c in clouds]),
+    )
+
+    # small synthetic scenes: inputs are regenerated from the seed, only the
+    # oracle's outputs are stored
+    out = {}
+    for name, (nc, npts, ragged) in {"syn_a": (3, 200, True), "syn_b": (4, 256, False)}.items():
+        s = make_scene(nc, npts, seed=7 + nc, ragged=ragged)
+        o = O.OracleScene(s.clouds, s.base_T_flange)
+        rng = np.random.Generator(np.random.PCG64(99))
+        poses = s.pose_init + rng.normal(0, 1, (32, 6)) * np.array([0.004] * 3 + [0.02] * 3)
+        costs = [o.get_error(p, s.plane) for p in poses]
+        g3 = O.make_grid([-20] * 3 + [-5] * 3, [20] * 3 + [5] * 3, [3] * 6)
+        bi, bc, bp, gcost = o.grid_search(s.plane, s.pose_init, g3, want_costs=True)
+        out[name] = {
+            "n_clouds": nc, "n_points": npts, "ragged": ragged, "seed": 7 + nc,
+            "poses": poses.tolist(), "costs": costs,
+            "grid3_best": bi, "grid3_cost": bc, "grid3_pose": bp.tolist(),
+            "grid3_costs_sum": float(np.sum(gcost)),
+            "plane_fit": O.fit_plane(o.combined_cloud(s.pose_init)).tolist(),
+        }
+    json.dump(out, open(os.path.join(OUT, "synthetic.json"), "w"), indent=1)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""CPU tests of the C-ABI library: it loads, exports every declared symbol,
+and its host-side logic (grid decoding, pose matrix, merge) matches the oracle.
+No compute entry point is exercised here (that needs a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ccal.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccal_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(ccal):
+    lib = ccal.load_library()
+    names = declared_symbols()
+    assert "ccal_grid_search" in names and "ccal_eval" in names and len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ccal.h but not exported"
+    # and the binding covers all of them
+    from cameracalibration_amd.binding import SIGNATURES
+    assert sorted(SIGNATURES) == names
+
+
+def test_grid_pose_and_size_match_oracle(ccal, oracle):
+    g = ccal.Grid.default()
+    og = oracle.grid_default()
+    assert g.size == 11 ** 6 == oracle.lib().orc_grid_size(og)
+    base = np.array([0.0204504, 0.111258, 0.0505291, -3.15376, -0.0280023, 1.58043])
+    rng = np.random.default_rng(0)
+    for idx in [0, 1, 10, 11, 121, 11 ** 6 - 1] + list(rng.integers(0, 11 ** 6, 50)):
+        np.testing.assert_array_equal(ccal.grid_pose(g, base, int(idx)),
+                                      oracle.grid_pose(og, base, int(idx)))
+    g2 = ccal.Grid.make([-20, -20, -24, -5, -5, -6], [2, 2, 2, 0.5, 0.5, 0.5], [20, 20, 25, 20, 20, 25])
+    og2 = oracle.make_grid([-20, -20, -24, -5, -5, -6], [2, 2, 2, 0.5, 0.5, 0.5], [20, 20, 25, 20, 20, 25])
+    assert g2.size == 10 ** 8
+    for idx in rng.integers(0, 10 ** 8, 50):
+        np.testing.assert_array_equal(ccal.grid_pose(g2, base, int(idx)),
+                                      oracle.grid_pose(og2, base, int(idx)))
+
+
+def test_pose_matrix_bit_equal_to_oracle(ccal, oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        pose = rng.normal(0, 1, 6) * np.array([0.5, 0.5, 0.5, 3.0, 1.5, 3.0])
+        np.testing.assert_array_equal(ccal.pose_to_matrix(pose), oracle.pose_to_matrix(pose))
+
+
+def test_argmin_merge(ccal):
+    from cameracalibration_amd.binding import argmin_merge
+    assert argmin_merge([3.0, 1.0, 1.0, 2.0], [5, 9, 7, 1]) == 2      # tie -> lowest index
+    assert argmin_merge([3.0, 1.0], [-1, -1]) == -1                   # empty shards
+    assert argmin_merge([1e9, 0.5], [-1, 4]) == 1
+
+
+def test_status_strings_and_no_device_behaviour(ccal):
+    lib = ccal.load_library()
+    assert lib.ccal_status_string(0) == b"ok"
+    assert lib.ccal_status_string(-2) == b"device error"
+    if ccal.device_count() == 0:
+        # the product must fail loudly without a GPU, never fall back
+        with pytest.raises(ccal.CcalError):
+            ccal.Optimizer(0)
+
+
+def test_gd_default_options(ccal):
+    o = ccal.GdOptions.default()
+    assert (o.max_iterations, o.min_gradient_len, o.min_step_len, o.momentum) == (10000, 1e-6, 1e-6, 0.4)
+    assert o.fd_eps == np.sqrt(np.finfo(np.float64).eps)
+    assert (o.wolfe_decrease, o.wolfe_c1, o.wolfe_c2) == (0.8, 1e-4, 0.9)
