@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void wgen_kernel(Source src, int64_t n_valid, 
 // point groups (their loads coalesce in L1/L2), split `by` of every cloud.
 // Output: partial[by][candidate] = sum_j scale_j * sum_{i in split} |w.p|.
 template <int NA>
-__global__ __launch_bounds__(256) void residual_mfma_kernel(
+__global__ __launch_bounds__(256, 3) void residual_mfma_kernel(
     const float* __restrict__ W, const f32x4* __restrict__ groups,
     const int* __restrict__ group_off, const double* __restrict__ scale,
     double* __restrict__ partial, int n_clouds, int n_ctiles, int n_splits)
@@ -173,11 +173,17 @@ __global__ __launch_bounds__(256) void residual_mfma_kernel(
         // outstanding load is the next group's prefetch (vmcnt(0), others max).
         __builtin_amdgcn_s_waitcnt(0x0F70);
         int since = 0;
-        // Two-deep software pipeline: the |d| adds of MFMA k are issued after
-        // MFMAs k+1 and k+2, which covers the matrix pipe's result latency
-        // without idle slots.  The last two results of a group are carried into
-        // the next iteration (they start as zero, and |0| adds nothing).
-        f32x4 carry0 = zero, carry1 = zero;
+        // The f32 MFMA and the VALU adds do not overlap on a SIMD, and every
+        // switch between them costs a few cycles, so they are issued in bursts:
+        // kBurst MFMAs back to back, then the 4*kBurst |d| adds of the PREVIOUS
+        // burst (whose results have long landed, so no wait states are needed).
+        // The last burst of a group is carried into the next loop trip; the
+        // carry starts as zero, and |0| adds nothing.
+        constexpr int kBurst = 4;
+        static_assert(NA % kBurst == 0, "candidate tiles per wave must be a multiple of the burst");
+        f32x4 carry[kBurst];
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) carry[q] = zero;
         for (int g = gb; g < ge; ++g) {
             // register double buffer: fetch the next group before using this one
             f32x4 bn = b;
@@ -185,17 +191,22 @@ __global__ __launch_bounds__(256) void residual_mfma_kernel(
             gp += 64;
             f32x4 d[4 * NA];
 #pragma unroll
-            for (int idx = 0; idx < 4 * NA; ++idx) {
-                d[idx] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[idx % NA], b[idx / NA], zero, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                const f32x4 done = idx == 0 ? carry0 : (idx == 1 ? carry1 : d[idx >= 2 ? idx - 2 : 0]);
-                const int a = (idx + 4 * NA - 2) % NA;
+            for (int i0 = 0; i0 < 4 * NA; i0 += kBurst) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[a][r] += __builtin_fabsf(done[r]);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                for (int q = 0; q < kBurst; ++q)
+                    d[i0 + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(i0 + q) % NA], b[(i0 + q) / NA], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, kBurst, 0);
+#pragma unroll
+                for (int q = 0; q < kBurst; ++q) {
+                    const f32x4 done = i0 == 0 ? carry[q] : d[i0 == 0 ? 0 : i0 - kBurst + q];
+                    const int a = (i0 + 4 * NA - kBurst + q) % NA;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][r] += __builtin_fabsf(done[r]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * kBurst, 0);
             }
-            carry0 = d[4 * NA - 2];
-            carry1 = d[4 * NA - 1];
+#pragma unroll
+            for (int q = 0; q < kBurst; ++q) carry[q] = d[4 * NA - kBurst + q];
             b = bn;
             if (++since == kFlushGroups) {
                 since = 0;
@@ -209,10 +220,9 @@ __global__ __launch_bounds__(256) void residual_mfma_kernel(
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[NA - 2][r] += __builtin_fabsf(carry0[r]);
-            acc[NA - 1][r] += __builtin_fabsf(carry1[r]);
-        }
+        for (int q = 0; q < kBurst; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[NA - kBurst + q][r] += __builtin_fabsf(carry[q][r]);
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll

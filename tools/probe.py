@@ -21,6 +21,7 @@ def main():
               f"total_dev {st.total_ms:.1f} ms  res/s(kernel) {st.residuals/st.kernel_ms*1e3:.3e} "
               f"frac {st.residuals*8/st.kernel_ms*1e3/157.3e12:.3f} rescored {st.n_rescored} best {idx} {cost:.6e}", flush=True)
     print("true pose err", pose - s.pose_true)
+    if len(sys.argv) <= 4: return
     t = time.time(); r = opt.gradient_descent(pose); print("gd", r.iterations, r.converged, r.fval, r.n_evals, time.time() - t, r.xval - s.pose_true)
 
 main()
