@@ -24,5 +24,8 @@ from .binding import (  # noqa: F401
     lib_path,
     load_library,
     pose_to_matrix,
+    read_point_cloud,
+    run_config,
+    voxel_grid,
 )
 from .synthetic import SyntheticScene, make_scene  # noqa: F401

@@ -155,6 +155,10 @@ SIGNATURES = {
         [_CTX, C.c_int, C.c_int, C.c_int, _D, _P(GdOptions), _P(_GdResultC)],
     ),
     "ccal_pose_to_matrix": (None, [_D, _D]),
+    "ccal_read_point_cloud": (C.c_int, [C.c_char_p, C.c_char_p, _P(_F), _P(C.c_size_t)]),
+    "ccal_voxel_grid": (C.c_int, [_F, C.c_size_t, C.c_float, _F, _P(C.c_size_t)]),
+    "ccal_free": (None, [C.c_void_p]),
+    "ccal_run_config": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
 }
 
 
@@ -358,3 +362,38 @@ def argmin_merge(costs: Sequence[float], indices: Sequence[int]) -> int:
     c = np.ascontiguousarray(costs, dtype=np.float64)
     i = np.ascontiguousarray(indices, dtype=np.int64)
     return int(load_library().ccal_argmin_merge(len(c), _dptr(c), i.ctypes.data_as(_P(C.c_int64))))
+
+
+def read_point_cloud(filename: str, metric: str = "m") -> np.ndarray:
+    """Cloud file (.ply / .pcd / .xyz) -> (N,3) float32, as readPointCloud (helpers.cpp:108-207)."""
+    lib = load_library()
+    ptr = _F()
+    n = C.c_size_t(0)
+    rc = lib.ccal_read_point_cloud(filename.encode(), metric.encode(), C.byref(ptr), C.byref(n))
+    if rc != 0:
+        raise CcalError(rc, f"cannot read {filename}")
+    try:
+        out = np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy() if n.value else np.zeros(0, np.float32)
+    finally:
+        lib.ccal_free(ptr)
+    return out.reshape(-1, 3)
+
+
+def voxel_grid(xyz: np.ndarray, leaf: float = 0.02) -> np.ndarray:
+    a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(a)
+    n = C.c_size_t(0)
+    rc = load_library().ccal_voxel_grid(a.ctypes.data_as(_F), a.shape[0], float(leaf),
+                                        out.ctypes.data_as(_F), C.byref(n))
+    if rc != 0:
+        raise CcalError(rc, "voxel_grid")
+    return out[: n.value].copy()
+
+
+def run_config(config: str, results: str, errors: str, verbose: bool = False) -> None:
+    """The whole optimiser run (the CLI's body) as a library call."""
+    buf = C.create_string_buffer(1024)
+    rc = load_library().ccal_run_config(config.encode(), results.encode(), errors.encode(),
+                                        int(verbose), buf, len(buf))
+    if rc != 0:
+        raise CcalError(rc, buf.value.decode(errors="replace"))

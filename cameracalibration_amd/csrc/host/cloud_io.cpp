@@ -1,0 +1,416 @@
+// cloud_io.cpp -- see cloud_io.hpp for the reference lines restated here.
+#include "cloud_io.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace ccal_host {
+
+double metric_scale(const std::string& metric)
+{
+    if (metric == "mm") return 1000.0;
+    if (metric == "cm") return 100.0;
+    return 1.0;
+}
+
+namespace {
+
+std::string lower(std::string s)
+{
+    for (auto& c : s) c = (char)std::tolower((unsigned char)c);
+    return s;
+}
+
+std::vector<std::string> split_ws(const std::string& line)
+{
+    std::vector<std::string> out;
+    std::istringstream is(line);
+    std::string t;
+    while (is >> t) out.push_back(t);
+    return out;
+}
+
+struct Prop {
+    std::string name;
+    int size = 0;       // bytes, 0 for list properties
+    char kind = 'f';    // 'f' float, 'd' double, 'i' signed int, 'u' unsigned int
+    bool is_list = false;
+};
+
+bool scalar_type(const std::string& t, int& size, char& kind)
+{
+    static const struct { const char* n; int s; char k; } tbl[] = {
+        {"char", 1, 'i'}, {"int8", 1, 'i'}, {"uchar", 1, 'u'}, {"uint8", 1, 'u'},
+        {"short", 2, 'i'}, {"int16", 2, 'i'}, {"ushort", 2, 'u'}, {"uint16", 2, 'u'},
+        {"int", 4, 'i'}, {"int32", 4, 'i'}, {"uint", 4, 'u'}, {"uint32", 4, 'u'},
+        {"float", 4, 'f'}, {"float32", 4, 'f'}, {"double", 8, 'd'}, {"float64", 8, 'd'}};
+    for (auto& e : tbl)
+        if (t == e.n) { size = e.s; kind = e.k; return true; }
+    return false;
+}
+
+double load_scalar(const unsigned char* p, int size, char kind, bool swap)
+{
+    unsigned char b[8];
+    std::memcpy(b, p, size);
+    if (swap) std::reverse(b, b + size);
+    switch (kind) {
+    case 'f': { float v; std::memcpy(&v, b, 4); return v; }
+    case 'd': { double v; std::memcpy(&v, b, 8); return v; }
+    case 'i':
+        if (size == 1) { int8_t v; std::memcpy(&v, b, 1); return v; }
+        if (size == 2) { int16_t v; std::memcpy(&v, b, 2); return v; }
+        { int32_t v; std::memcpy(&v, b, 4); return v; }
+    default:
+        if (size == 1) { uint8_t v; std::memcpy(&v, b, 1); return v; }
+        if (size == 2) { uint16_t v; std::memcpy(&v, b, 2); return v; }
+        { uint32_t v; std::memcpy(&v, b, 4); return v; }
+    }
+}
+
+bool host_is_little_endian()
+{
+    const uint16_t one = 1;
+    return *reinterpret_cast<const unsigned char*>(&one) == 1;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// PLY (ascii, binary_little_endian, binary_big_endian); vertex x,y,z of any
+// scalar type, other elements skipped.
+// ---------------------------------------------------------------------------
+Cloud read_ply(const std::string& filename)
+{
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + filename);
+    std::string line;
+    if (!std::getline(f, line) || split_ws(line).empty() || split_ws(line)[0] != "ply")
+        throw std::runtime_error(filename + ": not a PLY file");
+    struct Element { std::string name; size_t count = 0; std::vector<Prop> props; };
+    std::vector<Element> elems;
+    std::string format;
+    while (std::getline(f, line)) {
+        auto t = split_ws(line);
+        if (t.empty()) continue;
+        if (t[0] == "end_header") break;
+        if (t[0] == "format" && t.size() >= 2) format = t[1];
+        else if (t[0] == "element" && t.size() >= 3) {
+            Element e;
+            e.name = t[1];
+            e.count = (size_t)std::strtoull(t[2].c_str(), nullptr, 10);
+            elems.push_back(e);
+        } else if (t[0] == "property" && !elems.empty()) {
+            Prop p;
+            if (t.size() >= 5 && t[1] == "list") { p.is_list = true; p.name = t[4]; }
+            else if (t.size() >= 3) {
+                if (!scalar_type(t[1], p.size, p.kind))
+                    throw std::runtime_error(filename + ": unknown PLY type " + t[1]);
+                p.name = t[2];
+            }
+            elems.back().props.push_back(p);
+        }
+    }
+    if (format != "ascii" && format != "binary_little_endian" && format != "binary_big_endian")
+        throw std::runtime_error(filename + ": unsupported PLY format '" + format + "'");
+    const bool ascii = format == "ascii";
+    const bool swap = !ascii && ((format == "binary_little_endian") != host_is_little_endian());
+
+    Cloud out;
+    for (const Element& e : elems) {
+        int ix = -1, iy = -1, iz = -1, rec = 0;
+        bool has_list = false;
+        std::vector<int> offs;
+        for (size_t i = 0; i < e.props.size(); ++i) {
+            offs.push_back(rec);
+            if (e.props[i].is_list) has_list = true;
+            rec += e.props[i].size;
+            if (e.props[i].name == "x") ix = (int)i;
+            if (e.props[i].name == "y") iy = (int)i;
+            if (e.props[i].name == "z") iz = (int)i;
+        }
+        const bool is_vertex = e.name == "vertex";
+        if (is_vertex && (ix < 0 || iy < 0 || iz < 0))
+            throw std::runtime_error(filename + ": vertex element without x/y/z");
+        if (ascii) {
+            for (size_t r = 0; r < e.count; ++r) {
+                if (!std::getline(f, line)) throw std::runtime_error(filename + ": truncated PLY body");
+                if (!is_vertex) continue;
+                auto t = split_ws(line);
+                if ((int)t.size() <= std::max(ix, std::max(iy, iz)))
+                    throw std::runtime_error(filename + ": short vertex line");
+                out.push_back(std::strtof(t[ix].c_str(), nullptr));
+                out.push_back(std::strtof(t[iy].c_str(), nullptr));
+                out.push_back(std::strtof(t[iz].c_str(), nullptr));
+            }
+        } else {
+            if (has_list) {
+                if (is_vertex) throw std::runtime_error(filename + ": list property in a binary vertex element");
+                // a variable-size element after the vertices cannot be skipped blindly,
+                // but nothing after it is needed either
+                if (!out.empty()) break;
+                throw std::runtime_error(filename + ": list element before the vertices");
+            }
+            std::vector<unsigned char> buf((size_t)rec * e.count);
+            f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+            if ((size_t)f.gcount() != buf.size()) throw std::runtime_error(filename + ": truncated PLY body");
+            if (!is_vertex) continue;
+            out.reserve(out.size() + 3 * e.count);
+            for (size_t r = 0; r < e.count; ++r) {
+                const unsigned char* p = buf.data() + r * (size_t)rec;
+                out.push_back((float)load_scalar(p + offs[ix], e.props[ix].size, e.props[ix].kind, swap));
+                out.push_back((float)load_scalar(p + offs[iy], e.props[iy].size, e.props[iy].kind, swap));
+                out.push_back((float)load_scalar(p + offs[iz], e.props[iz].size, e.props[iz].kind, swap));
+            }
+        }
+        if (is_vertex) break;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// PCD v0.7 (DATA ascii | binary), generic field table
+// ---------------------------------------------------------------------------
+Cloud read_pcd(const std::string& filename)
+{
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + filename);
+    std::vector<std::string> fields, types;
+    std::vector<int> sizes, counts;
+    size_t points = 0, width = 0, height = 1;
+    bool have_points = false;
+    std::string data, line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        auto t = split_ws(line);
+        if (t.empty() || t[0][0] == '#') continue;
+        const std::string key = t[0];
+        if (key == "FIELDS") fields.assign(t.begin() + 1, t.end());
+        else if (key == "SIZE") for (size_t i = 1; i < t.size(); ++i) sizes.push_back(std::atoi(t[i].c_str()));
+        else if (key == "TYPE") types.assign(t.begin() + 1, t.end());
+        else if (key == "COUNT") for (size_t i = 1; i < t.size(); ++i) counts.push_back(std::atoi(t[i].c_str()));
+        else if (key == "WIDTH" && t.size() > 1) width = (size_t)std::strtoull(t[1].c_str(), nullptr, 10);
+        else if (key == "HEIGHT" && t.size() > 1) height = (size_t)std::strtoull(t[1].c_str(), nullptr, 10);
+        else if (key == "POINTS" && t.size() > 1) { points = (size_t)std::strtoull(t[1].c_str(), nullptr, 10); have_points = true; }
+        else if (key == "DATA" && t.size() > 1) { data = lower(t[1]); break; }
+    }
+    if (!have_points) points = width * height;
+    if (fields.empty() || sizes.size() != fields.size() || types.size() != fields.size())
+        throw std::runtime_error(filename + ": malformed PCD header");
+    if (counts.empty()) counts.assign(fields.size(), 1);
+    if (counts.size() != fields.size()) throw std::runtime_error(filename + ": malformed PCD COUNT");
+    int ix = -1, iy = -1, iz = -1, rec = 0, col = 0;
+    std::vector<int> offs, cols;
+    for (size_t i = 0; i < fields.size(); ++i) {
+        offs.push_back(rec);
+        cols.push_back(col);
+        rec += sizes[i] * counts[i];
+        col += counts[i];
+        if (fields[i] == "x") ix = (int)i;
+        if (fields[i] == "y") iy = (int)i;
+        if (fields[i] == "z") iz = (int)i;
+    }
+    if (ix < 0 || iy < 0 || iz < 0) throw std::runtime_error(filename + ": PCD without x/y/z fields");
+    auto kind_of = [&](int i) -> char {
+        const char t = types[i].empty() ? 'F' : types[i][0];
+        if (t == 'F') return sizes[i] == 8 ? 'd' : 'f';
+        return t == 'I' ? 'i' : 'u';
+    };
+    Cloud out;
+    out.reserve(points * 3);
+    if (data == "ascii") {
+        for (size_t r = 0; r < points; ++r) {
+            if (!std::getline(f, line)) throw std::runtime_error(filename + ": truncated PCD body");
+            auto t = split_ws(line);
+            if ((int)t.size() < col) throw std::runtime_error(filename + ": short PCD line");
+            out.push_back(std::strtof(t[cols[ix]].c_str(), nullptr));
+            out.push_back(std::strtof(t[cols[iy]].c_str(), nullptr));
+            out.push_back(std::strtof(t[cols[iz]].c_str(), nullptr));
+        }
+    } else if (data == "binary") {
+        std::vector<unsigned char> buf((size_t)rec * points);
+        f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
+        if ((size_t)f.gcount() != buf.size()) throw std::runtime_error(filename + ": truncated PCD body");
+        const bool swap = !host_is_little_endian();
+        for (size_t r = 0; r < points; ++r) {
+            const unsigned char* p = buf.data() + r * (size_t)rec;
+            out.push_back((float)load_scalar(p + offs[ix], sizes[ix], kind_of(ix), swap));
+            out.push_back((float)load_scalar(p + offs[iy], sizes[iy], kind_of(iy), swap));
+            out.push_back((float)load_scalar(p + offs[iz], sizes[iz], kind_of(iz), swap));
+        }
+    } else {
+        throw std::runtime_error(filename + ": unsupported PCD DATA '" + data + "'");
+    }
+    return out;
+}
+
+// src/helpers.cpp:168-194: skip the first line; each following non-empty line is
+// "<token> x,y,z ..."; coordinates = stof / scale.
+Cloud read_xyz_text(const std::string& filename, double scale)
+{
+    std::ifstream f(filename);
+    if (!f) throw std::runtime_error("cannot open " + filename);
+    std::string line;
+    std::getline(f, line);
+    Cloud out;
+    while (std::getline(f, line) && !line.empty()) {
+        size_t sp = line.find(' ');
+        if (sp == std::string::npos) throw std::runtime_error(filename + ": malformed xyz line");
+        size_t sp2 = line.find(' ', sp + 1);
+        std::string tok = line.substr(sp + 1, sp2 == std::string::npos ? std::string::npos : sp2 - sp - 1);
+        float v[3];
+        size_t pos = 0;
+        for (int k = 0; k < 3; ++k) {
+            size_t comma = tok.find(',', pos);
+            std::string piece = tok.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+            char* endp = nullptr;
+            float s = std::strtof(piece.c_str(), &endp);
+            if (endp == piece.c_str()) throw std::runtime_error(filename + ": malformed xyz coordinate");
+            v[k] = (float)((double)s / scale);
+            pos = comma == std::string::npos ? tok.size() : comma + 1;
+        }
+        out.insert(out.end(), v, v + 3);
+    }
+    return out;
+}
+
+// src/helpers.cpp:108-207
+Cloud read_point_cloud(const std::string& filename, const std::string& metric)
+{
+    const double scale = metric_scale(metric);
+    size_t dot = filename.rfind('.');
+    const std::string type = lower(dot == std::string::npos ? filename : filename.substr(dot + 1));
+    Cloud c;
+    if (type == "pcd") c = read_pcd(filename);
+    else if (type == "ply") c = read_ply(filename);
+    else if (type == "xyz") return read_xyz_text(filename, scale);
+    else throw std::runtime_error("Format not supported: " + filename);
+    if (metric != "m")
+        for (auto& v : c) v = (float)((double)v / scale);
+    return c;
+}
+
+Cloud filter_z(const Cloud& in, float z_max)
+{
+    Cloud out;
+    out.reserve(in.size());
+    for (size_t i = 0; i + 2 < in.size(); i += 3)
+        if (in[i + 2] <= z_max) out.insert(out.end(), in.begin() + i, in.begin() + i + 3);
+    return out;
+}
+
+Cloud voxel_grid(const Cloud& in, float leaf)
+{
+    const size_t n = in.size() / 3;
+    Cloud out;
+    if (n == 0) return out;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const float v = in[3 * i + k];
+            if (!std::isfinite(v)) continue;
+            mn[k] = std::min(mn[k], v);
+            mx[k] = std::max(mx[k], v);
+        }
+    int64_t minb[3], div[3];
+    for (int k = 0; k < 3; ++k) {
+        minb[k] = (int64_t)std::floor(mn[k] * inv);
+        div[k] = (int64_t)std::floor(mx[k] * inv) - minb[k] + 1;
+    }
+    struct Rec { int64_t key; uint32_t idx; };
+    std::vector<Rec> rec;
+    rec.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float* p = &in[3 * i];
+        if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+        const int64_t i0 = (int64_t)(std::floor(p[0] * inv) - (float)minb[0]);
+        const int64_t i1 = (int64_t)(std::floor(p[1] * inv) - (float)minb[1]);
+        const int64_t i2 = (int64_t)(std::floor(p[2] * inv) - (float)minb[2]);
+        rec.push_back({i0 + i1 * div[0] + i2 * div[0] * div[1], (uint32_t)i});
+    }
+    std::stable_sort(rec.begin(), rec.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    for (size_t i = 0; i < rec.size();) {
+        size_t j = i;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (; j < rec.size() && rec[j].key == rec[i].key; ++j) {
+            const float* p = &in[3 * (size_t)rec[j].idx];
+            sx += p[0]; sy += p[1]; sz += p[2];
+        }
+        const float cnt = (float)(j - i);
+        out.push_back(sx / cnt);
+        out.push_back(sy / cnt);
+        out.push_back(sz / cnt);
+        i = j;
+    }
+    return out;
+}
+
+// src/camera_calibration_optimization.cpp:81-93 and src/helpers.cpp:244-251
+int parse_pose_csv(const std::string& line, double scale, bool angle_is_degree, double pose[6])
+{
+    int n = 0;
+    size_t pos = 0;
+    while (pos <= line.size() && n < 6) {
+        size_t comma = line.find(',', pos);
+        std::string piece = line.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        char* endp = nullptr;
+        const float f = std::strtof(piece.c_str(), &endp);  // std::stof
+        if (endp == piece.c_str()) break;
+        if (n < 3) pose[n] = f / scale;
+        else {
+            double value = f;
+            if (angle_is_degree) value = (int)value * 3.141592 / 180;  // degreeToRadian(int)
+            pose[n] = value;
+        }
+        ++n;
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+    }
+    return n;
+}
+
+std::vector<std::vector<double>> read_transformations(const std::string& filename,
+                                                      const std::string& metric)
+{
+    std::ifstream f(filename);
+    if (!f) throw std::runtime_error("cannot open " + filename);
+    const double scale = metric_scale(metric);
+    std::vector<std::vector<double>> out;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) break;   // `while(getline(file,trans)&&trans.size())`
+        double pose[6] = {0, 0, 0, 0, 0, 0};
+        if (parse_pose_csv(line, scale, false, pose) < 6)
+            throw std::runtime_error(filename + ": a transformation needs 6 comma-separated values");
+        out.emplace_back(pose, pose + 6);
+    }
+    return out;
+}
+
+// src/camera_calibration_optimization.cpp:140-146
+int file_id(const std::string& filename)
+{
+    size_t slash = filename.rfind('/');
+    std::string file = slash == std::string::npos ? filename : filename.substr(slash + 1);
+    file = file.substr(0, file.find('.'));
+    size_t us = file.find('_');
+    if (us == std::string::npos) throw std::runtime_error("no '_<id>' in cloud file name " + filename);
+    std::string id = file.substr(us + 1);
+    id = id.substr(0, id.find('_'));
+    try {
+        return std::stoi(id);
+    } catch (...) {
+        throw std::runtime_error("no numeric id in cloud file name " + filename);
+    }
+}
+
+} // namespace ccal_host

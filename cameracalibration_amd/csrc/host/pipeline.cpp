@@ -1,0 +1,298 @@
+// pipeline.cpp -- the optimiser run: config -> clouds -> plane -> discrete search
+// -> gradient descent -> results.txt / new_experiments_errors.txt.
+//
+// Host-side mirror of src/camera_calibration_optimization.cpp: main (:560-581),
+// Optimizer::getInputs (:148-278), discreteCombinatorialOptimization (:526-558),
+// gradientDescent (:411-465), gradientDescentWithPlane (:466-524) and
+// Optimizer::printError (:348-407).  Every objective value, the plane fit and
+// both searches go through the C ABI of include/ccal.h; this file only parses,
+// uploads, and writes the two text files in the reference's format (default
+// ostream formatting, append mode).
+#include "../../../include/ccal.h"
+#include "cloud_io.hpp"
+#include "xml_lite.hpp"
+
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace ccal_host;
+
+namespace {
+
+struct Inputs {
+    std::vector<Cloud> raw, down;
+    std::vector<double> base_T_flange;   // per cloud, already mapped (:290)
+    double pose_init[6];
+    ccal_grid grid;
+    int n_gpus = 1;
+    ccal_gd_opts gd;
+};
+
+std::string slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open config " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+double num(const XmlNode& root, const std::string& path, double dflt)
+{
+    const XmlNode* n = root.find(path);
+    if (!n) return dflt;
+    return std::strtod(trim(n->text).c_str(), nullptr);
+}
+
+// Optimizer::getInputs (:148-237) without the plane fit
+Inputs load_inputs(const std::string& config_file, bool chatty)
+{
+    Inputs in;
+    const std::string xml = slurp(config_file);
+    auto root = XmlParser(xml).parse();
+    if (chatty) std::cout << "Config File: " << config_file << std::endl;
+    const std::string camera_metric = trim(root->get("data.camera.metric", "m"));   // :156
+    const XmlNode* clouds = root->find("data.camera.clouds");
+    if (!clouds || clouds->children.empty()) throw std::runtime_error("config: no data.camera.clouds entries");
+
+    std::vector<int> mapping;
+    for (const auto& c : clouds->children) {                                       // :158
+        const std::string filename = trim(c->text);
+        const int cloud_id = file_id(filename);                                    // :161
+        if (chatty) std::cout << "Cloud Number: " << cloud_id << std::endl;
+        mapping.push_back(cloud_id - 1);                                           // :163
+        Cloud all = read_point_cloud(filename, camera_metric);                     // :165
+        Cloud kept = filter_z(all, 0.8f);                                          // :167-169
+        if (kept.empty()) throw std::runtime_error(filename + ": no points with z <= 0.8");
+        Cloud ds = voxel_grid(kept, 0.02f);                                        // :199-203
+        if (chatty) std::cout << "Filtered Clouds Size: " << ds.size() / 3 << std::endl;
+        in.raw.push_back(std::move(kept));
+        in.down.push_back(std::move(ds));
+    }
+
+    const XmlNode* ik = root->find("data.camera.transformations.inverse_kinematics.location");
+    if (!ik) throw std::runtime_error("config: inverse_kinematics.location missing");  // ptree::get throws
+    const std::string ik_file = trim(ik->text);
+    const std::string ik_metric = trim(root->get("data.camera.transformations.inverse_kinematics.metric", "m"));
+    auto iks = read_transformations(ik_file, ik_metric);                           // :210
+    in.base_T_flange.resize(16 * mapping.size());
+    for (size_t k = 0; k < mapping.size(); ++k) {
+        if (mapping[k] < 0 || mapping[k] >= (int)iks.size())
+            throw std::runtime_error("cloud id " + std::to_string(mapping[k] + 1) + " has no row in " + ik_file);
+        ccal_pose_to_matrix(iks[mapping[k]].data(), &in.base_T_flange[16 * k]);
+    }
+
+    // getTransVector (:70-98)
+    const std::string s = "data.camera.transformations.approximate_transformation";
+    const std::string angle = trim(root->get(s + ".angle", "radian"));
+    const std::string metric = trim(root->get(s + ".metric", "m"));
+    const std::string value = root->get(s + ".value", "0,0,0,0,0,0");
+    for (double& v : in.pose_init) v = 0.0;
+    parse_pose_csv(value, metric_scale(metric), angle == "degree", in.pose_init);
+    if (chatty) {
+        std::cout << value << std::endl;
+        for (double v : in.pose_init) std::cout << v << " ";
+        std::cout << std::endl;
+    }
+
+    // optional extensions (absent -> the reference's fixed 11^6 grid, one GPU)
+    ccal_grid_default(&in.grid);
+    for (int k = 0; k < 6; ++k) {
+        const std::string grp = k < 3 ? "data.search.translation_mm" : "data.search.rotation_deg";
+        in.grid.min[k] = num(*root, grp + ".min", in.grid.min[k]);
+        in.grid.step[k] = num(*root, grp + ".step", in.grid.step[k]);
+        in.grid.count[k] = (int)num(*root, grp + ".count", in.grid.count[k]);
+    }
+    in.n_gpus = (int)num(*root, "data.device.gpus", 1);
+    ccal_gd_default_opts(&in.gd);
+    in.gd.max_iterations = (int)num(*root, "data.search.gd_max_iterations", in.gd.max_iterations);
+    return in;
+}
+
+struct Check {
+    ccal_ctx* ctx;
+    void operator()(int rc, const char* what) const
+    {
+        if (rc != CCAL_OK)
+            throw std::runtime_error(std::string(what) + ": " + (ctx ? ccal_last_error(ctx) : ccal_status_string(rc)));
+    }
+};
+
+void upload(ccal_ctx* ctx, int which, const std::vector<Cloud>& clouds, const std::vector<double>& B)
+{
+    std::vector<const float*> ptrs;
+    std::vector<size_t> sizes;
+    for (const auto& c : clouds) { ptrs.push_back(c.data()); sizes.push_back(c.size() / 3); }
+    Check{ctx}(ccal_upload_clouds(ctx, which, (int)clouds.size(), ptrs.data(), sizes.data(), B.data()), "upload");
+}
+
+// Optimizer::printError (:348-407)
+void print_error(ccal_ctx* ctx, const double pose[6], int n_clouds, std::ostream& errorfile)
+{
+    std::vector<double> mean(n_clouds), mx(n_clouds);
+    double cost;
+    Check{ctx}(ccal_eval(ctx, CCAL_DOWNSAMPLED, 1, pose, nullptr, &cost, mean.data(), mx.data()), "eval");
+    for (int j = 0; j < n_clouds; ++j)
+        errorfile << "Downsampled No: " << j << " Error Avg: " << mean[j] * 1000.0
+                  << " Errom Max: " << mx[j] * 1000.0 << std::endl;                  // :376
+    Check{ctx}(ccal_eval(ctx, CCAL_RAW, 1, pose, nullptr, &cost, mean.data(), mx.data()), "eval");
+    for (int j = 0; j < n_clouds; ++j)
+        errorfile << "Real No: " << j << " Error Avg: " << mean[j] * 1000.0
+                  << " Errom Max: " << mx[j] * 1000.0 << std::endl;                  // :404
+    errorfile << "--------------------------------------------" << std::endl;        // :406
+}
+
+} // namespace
+
+extern "C" int ccal_run_config(const char* config_path, const char* results_path,
+                               const char* errors_path, int verbose, char* errbuf, size_t errbuf_len)
+{
+    std::vector<ccal_ctx*> ctxs;
+    auto cleanup = [&]() { for (auto* c : ctxs) ccal_destroy(c); ctxs.clear(); };
+    try {
+        if (!config_path) throw std::runtime_error("null config path");
+        const bool chatty = verbose != 0;
+        std::ofstream outfile(results_path ? results_path : "results.txt", std::ios_base::app);            // :567
+        std::ofstream errorfile(errors_path ? errors_path : "new_experiments_errors.txt", std::ios_base::app);  // :569
+        if (!outfile || !errorfile) throw std::runtime_error("cannot open the result files for appending");
+        outfile << "Results: " << config_path << std::endl;                                                 // :571
+        errorfile << "Results: " << config_path << std::endl;                                               // :572
+
+        Inputs in = load_inputs(config_path, chatty);
+        const int C = (int)in.down.size();
+        const int avail = ccal_device_count();
+        if (avail < 1) throw std::runtime_error("no GPU visible: the optimiser has no CPU path");
+        const int n_gpus = std::max(1, std::min(in.n_gpus, avail));
+        for (int d = 0; d < n_gpus; ++d) {
+            ccal_ctx* c = nullptr;
+            Check{nullptr}(ccal_create(d, &c), "ccal_create");
+            ctxs.push_back(c);
+            upload(c, CCAL_DOWNSAMPLED, in.down, in.base_T_flange);
+        }
+        ccal_ctx* ctx = ctxs[0];
+        upload(ctx, CCAL_RAW, in.raw, in.base_T_flange);
+
+        // plane from every raw point carried to the base frame by the initial pose (:240-277)
+        float plane[4];
+        Check{ctx}(ccal_fit_plane_lsq(ctx, CCAL_RAW, in.pose_init, plane), "fit_plane_lsq");
+        for (auto* c : ctxs) Check{c}(ccal_set_plane(c, plane), "set_plane");
+        if (chatty) {
+            std::cout << "Plane Equation 2: " << std::endl;
+            for (int i = 0; i < 4; ++i) std::cout << plane[i] << " ";
+            std::cout << std::endl << "Starting optimization" << std::endl;
+        }
+
+        // ---- discreteCombinatorialOptimization (:526-558) -----------------------------
+        double true_err;
+        Check{ctx}(ccal_eval(ctx, CCAL_DOWNSAMPLED, 1, in.pose_init, nullptr, &true_err, nullptr, nullptr), "eval");
+        if (chatty) std::cout << "True: " << true_err;                                                      // :529
+        const int64_t total = ccal_grid_size(&in.grid);
+        if (total <= 0) throw std::runtime_error("config: empty search grid");
+        std::vector<double> costs(n_gpus, 1e9), poses(6 * (size_t)n_gpus);
+        std::vector<int64_t> idxs(n_gpus, -1);
+        std::vector<int> rcs(n_gpus, CCAL_OK);
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_gpus; ++d) {
+            const int64_t b = total * d / n_gpus, e = total * (d + 1) / n_gpus;
+            th.emplace_back([&, d, b, e]() {
+                rcs[d] = ccal_grid_search(ctxs[d], CCAL_DOWNSAMPLED, in.pose_init, &in.grid, b, e, &idxs[d],
+                                          &costs[d], &poses[6 * (size_t)d], nullptr);
+            });
+        }
+        for (auto& t : th) t.join();
+        for (int d = 0; d < n_gpus; ++d) Check{ctxs[d]}(rcs[d], "grid_search");
+        const int w = ccal_argmin_merge(n_gpus, costs.data(), idxs.data());
+        double best[6];
+        std::memcpy(best, w >= 0 ? &poses[6 * (size_t)w] : in.pose_init, sizeof best);
+        if (chatty) {
+            std::cout << "Error: " << (w >= 0 ? costs[w] : 1e9) << std::endl << "Best Transformation:" << std::endl;
+            for (double v : best) std::cout << v << " ";
+            std::cout << std::endl;
+        }
+        outfile << "Flange Transformation From Discrete Optimization" << std::endl;                         // :553
+        for (int i = 0; i < 5; ++i) outfile << best[i] << ", ";
+        outfile << best[5] << std::endl;
+
+        // ---- gradientDescent (:411-465) -----------------------------------------------
+        ccal_gd_result r6;
+        Check{ctx}(ccal_gd_minimize(ctx, CCAL_DOWNSAMPLED, 6, best, &in.gd, &r6), "gd_minimize");
+        if (chatty)
+            std::cout << "Done! Converged: " << (r6.converged ? "true" : "false") << " Iterations: " << r6.iterations
+                      << std::endl << "Final fval: " << r6.fval << std::endl;
+        outfile << "Gradient Descent on Flange Transformation..." << std::endl;
+        outfile << "Iterations: " << r6.iterations << " Converged: " << (r6.converged ? "true" : "false")
+                << " Final fval: " << r6.fval << std::endl;
+        outfile << "Flange Transformation" << std::endl;
+        for (int i = 0; i < 5; ++i) outfile << r6.xval[i] << ", ";
+        outfile << r6.xval[5] << std::endl;
+        outfile << "Plane Equation" << std::endl;
+        for (int i = 0; i < 3; ++i) outfile << plane[i] << ", ";
+        outfile << plane[3] << std::endl;
+        print_error(ctx, r6.xval, C, errorfile);                                                            // :464
+
+        // ---- gradientDescentWithPlane (:466-524) --------------------------------------
+        double x10[10];
+        std::memcpy(x10, r6.xval, 6 * sizeof(double));
+        for (int i = 0; i < 4; ++i) x10[6 + i] = plane[i];                                                  // :503-504
+        ccal_gd_result r10;
+        Check{ctx}(ccal_gd_minimize(ctx, CCAL_DOWNSAMPLED, 10, x10, &in.gd, &r10), "gd_minimize");
+        outfile << "Gradient Descent on Plane..." << std::endl;
+        outfile << "Iterations: " << r10.iterations << " Converged: " << (r10.converged ? "true" : "false")
+                << " Final fval: " << r10.fval << std::endl;
+        outfile << "Flange Transformation" << std::endl;
+        for (int i = 0; i < 5; ++i) outfile << r10.xval[i] << ", ";
+        outfile << r10.xval[5] << std::endl;
+        outfile << "Plane Equation" << std::endl;
+        for (int i = 0; i < 3; ++i) outfile << r10.xval[6 + i] << ", ";
+        outfile << r10.xval[9] << std::endl;
+        print_error(ctx, r10.xval, C, errorfile);                                                           // :523 (original plane)
+
+        outfile << "------------------------------------------------------" << std::endl;                 // :579
+        cleanup();
+        return CCAL_OK;
+    } catch (const std::exception& e) {
+        cleanup();
+        if (errbuf && errbuf_len) {
+            std::strncpy(errbuf, e.what(), errbuf_len - 1);
+            errbuf[errbuf_len - 1] = 0;
+        }
+        return CCAL_ERR_IO;
+    }
+}
+
+// Loader entry points of the C ABI (thin wrappers; see include/ccal.h)
+extern "C" int ccal_read_point_cloud(const char* filename, const char* metric, float** xyz_out, size_t* n_out)
+{
+    if (!filename || !xyz_out || !n_out) return CCAL_ERR_ARG;
+    try {
+        Cloud c = read_point_cloud(filename, metric ? metric : "m");
+        float* p = (float*)std::malloc(std::max<size_t>(c.size(), 1) * sizeof(float));
+        if (!p) return CCAL_ERR_IO;
+        std::memcpy(p, c.data(), c.size() * sizeof(float));
+        *xyz_out = p;
+        *n_out = c.size() / 3;
+        return CCAL_OK;
+    } catch (const std::exception&) {
+        *xyz_out = nullptr;
+        *n_out = 0;
+        return CCAL_ERR_IO;
+    }
+}
+
+extern "C" int ccal_voxel_grid(const float* xyz, size_t n, float leaf, float* xyz_out, size_t* n_out)
+{
+    if ((!xyz && n) || !xyz_out || !n_out || !(leaf > 0)) return CCAL_ERR_ARG;
+    Cloud in(xyz, xyz + 3 * n);
+    Cloud out = voxel_grid(in, leaf);
+    std::memcpy(xyz_out, out.data(), out.size() * sizeof(float));
+    *n_out = out.size() / 3;
+    return CCAL_OK;
+}
+
+extern "C" void ccal_free(void* p) { std::free(p); }

@@ -183,6 +183,28 @@ int  ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_starts,
                             const double* x0, const ccal_gd_opts* opts,
                             ccal_gd_result* results);
 
+/* ---- host-side ingest and the whole run -------------------------------------
+ * These three do not touch the GPU. */
+
+/* Cloud file -> malloc'ed AoS xyz (release with ccal_free).  Replaces
+ * InputUtilities::readPointCloud (helpers.cpp:108-207): format by extension
+ * (.pcd / .ply / .xyz), coordinates divided by 1000 ("mm") or 100 ("cm"). */
+int  ccal_read_point_cloud(const char* filename, const char* metric, float** xyz_out,
+                           size_t* n_out);
+/* Voxel-grid centroid filter standing in for pcl::VoxelGrid at
+ * camera_calibration_optimization.cpp:196-205 (leaf 0.02f).  xyz_out must hold
+ * n points; n_out receives the number of centroids. */
+int  ccal_voxel_grid(const float* xyz, size_t n, float leaf, float* xyz_out, size_t* n_out);
+void ccal_free(void* p);
+
+/* The optimiser executable as one call: replaces main() + getInputs() + the
+ * three drivers (camera_calibration_optimization.cpp:560-581, :148-278,
+ * :526-558, :411-524).  Reads the reference's XML config, appends to the two
+ * text files in the reference's format.  On failure returns a negative status
+ * and copies a message into errbuf. */
+int  ccal_run_config(const char* config_path, const char* results_path, const char* errors_path,
+                     int verbose, char* errbuf, size_t errbuf_len);
+
 /* Pose math shared with callers (helpers.cpp:45-71): ZYX pose -> 4x4. */
 void ccal_pose_to_matrix(const double pose[6], double T[16]);
 

@@ -1,0 +1,141 @@
+"""End-to-end GPU test of the camera_calibration_optimization executable: same
+config schema, same results.txt / new_experiments_errors.txt text as the
+reference's CLI (src/camera_calibration_optimization.cpp:560-581), checked
+line by line against the CPU oracle run on the same files."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cameracalibration_amd.synthetic import make_scene
+from tests.test_loader_cpu import write_pcd_binary, write_ply_binary
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "cameracalibration_amd", "camera_calibration_optimization")
+
+
+def g(v):
+    return "%g" % v          # default ostream formatting of a double / float
+
+
+def zyx_pose(T):
+    R = T[:3, :3]
+    return np.array([T[0, 3], T[1, 3], T[2, 3], np.arctan2(R[1, 0], R[0, 0]), -np.arcsin(R[2, 0]),
+                     np.arctan2(R[2, 1], R[2, 2])])
+
+
+def build_case(tmp, ccal):
+    s = make_scene(3, 20000, seed=77, ragged=True)
+    os.makedirs(tmp / "pc")
+    # document order 2,3,1 exercises mapping[k] = id - 1 (:161-163)
+    order = [2, 3, 1]
+    files = []
+    for k, cid in enumerate(order):
+        pts = s.clouds[k].copy()
+        pts[::997, 2] = 0.9                       # dropped by the z <= 0.8 filter
+        if cid == 3:
+            path = str(tmp / "pc" / ("cloud_%d.pcd" % cid))
+            write_pcd_binary(path, pts)
+        else:
+            path = str(tmp / "pc" / ("cloud_%d.ply" % cid))
+            write_ply_binary(path, pts)
+        files.append(path)
+    rows = [None] * 3
+    for k, cid in enumerate(order):
+        rows[cid - 1] = zyx_pose(s.base_T_flange[k]) * np.array([1000, 1000, 1000, 1, 1, 1])   # mm in the file
+    ik = tmp / "BaseToFlange.csv"
+    ik.write_text("".join(",".join("%.6f" % v for v in r) + "\n" for r in rows))
+    init = s.pose_init
+    cfg = tmp / "config.xml"
+    cfg.write_text(f"""<?xml version="1.0"?>
+<data>
+    <camera>
+        <transformations>
+           <inverse_kinematics>
+                <metric>mm</metric>
+                <location>{ik}</location>
+            </inverse_kinematics>
+            <approximate_transformation>
+                <angle>rad</angle>
+                <metric>m</metric>
+                <value>{",".join("%.6g" % v for v in init)}</value>
+            </approximate_transformation>
+        </transformations>
+        <metric>m</metric>
+        <clouds>
+            <pointcloud>{files[0]}</pointcloud>
+            <pointcloud>{files[1]}</pointcloud>
+            <pointcloud>{files[2]}</pointcloud>
+        </clouds>
+    </camera>
+    <!-- extension nodes; without them the run uses the reference's 11^6 grid -->
+    <search>
+        <translation_mm><min>-8</min><step>4</step><count>5</count></translation_mm>
+        <rotation_deg><min>-4</min><step>2</step><count>5</count></rotation_deg>
+        <gd_max_iterations>12</gd_max_iterations>
+    </search>
+</data>
+""")
+    return cfg, files, order, ik, init
+
+
+def oracle_expected(O, ccal, cfg, files, order, ik, init):
+    raw = []
+    for f in files:
+        a = ccal.read_point_cloud(f)
+        raw.append(a[a[:, 2] <= 0.8])
+    ds = [O.voxel_grid(c, 0.02) for c in raw]
+    ik_rows = [O.parse_pose_csv(l, scale=1000.0) for l in open(ik).read().split("\n") if l.strip()]
+    B = np.stack([O.pose_to_matrix(ik_rows[cid - 1]) for cid in order])
+    pose0 = O.parse_pose_csv(",".join("%.6g" % v for v in init))
+    sraw, sds = O.OracleScene(raw, B), O.OracleScene(ds, B)
+    plane = O.fit_plane(sraw.combined_cloud(pose0))
+    grid = O.make_grid([-8] * 3 + [-4] * 3, [4] * 3 + [2] * 3, [5] * 6)
+    _, _, best, _ = sds.grid_search(plane, pose0, grid)
+    o = O.gd_default_opts()
+    o.max_iterations = 12
+    r6 = sds.gd_minimize(plane, best, o)
+    x6 = np.array(r6.xval[:6])
+    r10 = sds.gd_minimize(plane, np.concatenate([x6, plane.astype(np.float64)]), o)
+    x10 = np.array(r10.xval[:10])
+    tf = lambda b: "true" if b else "false"
+    res = [f"Results: {cfg}", "Flange Transformation From Discrete Optimization", ", ".join(g(v) for v in best),
+           "Gradient Descent on Flange Transformation...",
+           f"Iterations: {r6.iterations} Converged: {tf(r6.converged)} Final fval: {g(r6.fval)}",
+           "Flange Transformation", ", ".join(g(v) for v in x6), "Plane Equation", ", ".join(g(v) for v in plane),
+           "Gradient Descent on Plane...",
+           f"Iterations: {r10.iterations} Converged: {tf(r10.converged)} Final fval: {g(r10.fval)}",
+           "Flange Transformation", ", ".join(g(v) for v in x10[:6]), "Plane Equation",
+           ", ".join(g(v) for v in x10[6:]), "-" * 54]
+    err = [f"Results: {cfg}"]
+    for x in (x6, x10[:6]):
+        for name, sc in (("Downsampled", sds), ("Real", sraw)):
+            mean, mx = sc.per_cloud_error(x, plane)
+            for j in range(3):
+                err.append(f"{name} No: {j} Error Avg: {g(mean[j] * 1000.0)} Errom Max: {g(mx[j] * 1000.0)}")
+        err.append("-" * 44)
+    return res, err, plane
+
+
+def test_cli_end_to_end(tmp_path, ccal, oracle, gpu_opt):
+    cfg, files, order, ik, init = build_case(tmp_path, ccal)
+    res, err, plane = oracle_expected(oracle, ccal, cfg, files, order, ik, init)
+    assert os.path.exists(CLI), "build the CLI with make -C cameracalibration_amd/csrc"
+    for run in (1, 2):                           # second run appends (:567-569)
+        p = subprocess.run([CLI, str(cfg)], cwd=tmp_path, capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr
+        got_res = open(tmp_path / "results.txt").read().split("\n")
+        got_err = open(tmp_path / "new_experiments_errors.txt").read().split("\n")
+        assert got_res == res * run + [""]
+        assert got_err == err * run + [""]
+    assert "True: " in p.stdout and "Starting optimization" in p.stdout
+
+
+def test_cli_usage_and_errors(tmp_path):
+    p = subprocess.run([CLI], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "Usage: optimizer_test <config file>" in p.stdout
+    p = subprocess.run([CLI, "missing.xml"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "cannot open config" in p.stderr

@@ -1,0 +1,141 @@
+"""CPU tests of the host-side ingest behind the C ABI (no GPU work): cloud
+readers for the three formats the reference accepts, metric scaling, the voxel
+grid against the oracle, config parsing through a failing run."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+REF_PLY = "/root/reference/example/calib_1/pointcloud/cloud_1.ply"
+REF_PCD = "/root/reference/example/example_data/pointcloud/pos_9.pcd"
+
+
+def write_ply_binary(path, pts, big_endian=False, extra_element=True):
+    e = ">" if big_endian else "<"
+    hdr = ["ply", "format binary_%s_endian 1.0" % ("big" if big_endian else "little"), "comment test",
+           "element vertex %d" % len(pts), "property float x", "property float y", "property float z"]
+    if extra_element:
+        hdr += ["element camera 1", "property float view_px", "property int viewportx"]
+    hdr += ["end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode())
+        f.write(pts.astype(e + "f4").tobytes())
+        if extra_element:
+            f.write(struct.pack(e + "fi", 1.0, 7))
+
+
+def write_ply_ascii(path, pts):
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty double x\nproperty double y\nproperty double z\n"
+                "property uchar red\nend_header\n" % len(pts))
+        for p in pts:
+            f.write("%.9g %.9g %.9g 255\n" % tuple(p))
+
+
+def write_pcd_binary(path, pts):
+    # the field table of the reference's example_data clouds: rgb _ x y z _ (32-byte records)
+    n = len(pts)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS rgb _ x y z _\nSIZE 4 1 4 4 4 1\n"
+           "TYPE F U F F F U\nCOUNT 1 12 1 1 1 4\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary\n" % (n, n))
+    rec = np.zeros((n, 32), dtype=np.uint8)
+    rec[:, 16:28] = pts.astype("<f4").view(np.uint8).reshape(n, 12)
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(rec.tobytes())
+
+
+def write_pcd_ascii(path, pts):
+    n = len(pts)
+    with open(path, "w") as f:
+        f.write("VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA ascii\n" % (n, n))
+        for p in pts:
+            f.write("%.9g %.9g %.9g\n" % tuple(p))
+
+
+@pytest.fixture()
+def pts():
+    rng = np.random.default_rng(12)
+    return rng.uniform(-0.4, 0.9, (1000, 3)).astype(np.float32)
+
+
+def test_ply_readers(ccal, pts, tmp_path):
+    p = str(tmp_path / "cloud_1.ply")
+    write_ply_binary(p, pts)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
+    write_ply_binary(p, pts, big_endian=True, extra_element=False)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
+    write_ply_ascii(p, pts)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
+    # metric scaling: float -> double divide -> float (helpers.cpp:159-165)
+    write_ply_binary(p, pts)
+    got = ccal.read_point_cloud(p, "mm")
+    np.testing.assert_array_equal(got, (pts.astype(np.float64) / 1000.0).astype(np.float32))
+
+
+def test_pcd_readers(ccal, pts, tmp_path):
+    p = str(tmp_path / "pos_3.pcd")
+    write_pcd_binary(p, pts)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
+    write_pcd_ascii(p, pts)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
+    got = ccal.read_point_cloud(p, "cm")
+    np.testing.assert_array_equal(got, (pts.astype(np.float64) / 100.0).astype(np.float32))
+
+
+def test_xyz_reader(ccal, pts, tmp_path):
+    p = str(tmp_path / "scan_2.xyz")
+    with open(p, "w") as f:
+        f.write("header line is skipped\n")
+        for i, q in enumerate(pts[:100]):
+            f.write("%d %.6f,%.6f,%.6f extra\n" % (i, q[0] * 1000, q[1] * 1000, q[2] * 1000))
+        f.write("\nignored after the first empty line\n")
+    got = ccal.read_point_cloud(p, "mm")
+    want = np.array([[np.float32(float(np.float32(float("%.6f" % (v * 1000)))) / 1000.0) for v in q] for q in pts[:100]],
+                    dtype=np.float32)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_unsupported_and_missing_files(ccal, tmp_path):
+    with pytest.raises(ccal.CcalError):
+        ccal.read_point_cloud(str(tmp_path / "nope_1.ply"))
+    bad = tmp_path / "cloud_1.obj"
+    bad.write_text("v 0 0 0\n")
+    with pytest.raises(ccal.CcalError):
+        ccal.read_point_cloud(str(bad))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PLY), reason="reference example data not present")
+def test_reference_example_files(ccal):
+    raw = open(REF_PLY, "rb").read()
+    h = raw.index(b"end_header\n") + 11
+    want = np.frombuffer(raw[h:h + 12 * 211566], dtype="<f4").reshape(-1, 3)
+    np.testing.assert_array_equal(ccal.read_point_cloud(REF_PLY), want)
+    pcd = ccal.read_point_cloud(REF_PCD)
+    assert pcd.shape == (112220, 3)
+    b = open(REF_PCD, "rb").read()
+    body = b[b.index(b"DATA binary\n") + 12:]
+    rec = np.frombuffer(body[:32 * 112220], dtype=np.uint8).reshape(-1, 32)
+    want = rec[:, 16:28].copy().view("<f4").reshape(-1, 3)
+    np.testing.assert_array_equal(pcd, want)
+
+
+def test_voxel_grid_matches_oracle(ccal, oracle, calib1):
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-0.2, 0.3, (50000, 3)).astype(np.float32)
+    np.testing.assert_array_equal(ccal.voxel_grid(pts, 0.02), oracle.voxel_grid(pts, 0.02))
+    sub = calib1["sub_0"]
+    np.testing.assert_array_equal(ccal.voxel_grid(sub, 0.02), oracle.voxel_grid(sub, 0.02))
+    assert ccal.voxel_grid(np.zeros((0, 3), np.float32)).shape == (0, 3)
+
+
+def test_run_config_reports_bad_inputs(ccal, tmp_path):
+    res, err = str(tmp_path / "results.txt"), str(tmp_path / "errors.txt")
+    with pytest.raises(ccal.CcalError, match="cannot open config"):
+        ccal.run_config(str(tmp_path / "missing.xml"), res, err)
+    cfg = tmp_path / "c.xml"
+    cfg.write_text("<?xml version='1.0'?><data><camera><clouds></clouds></camera></data>")
+    with pytest.raises(ccal.CcalError, match="no data.camera.clouds"):
+        ccal.run_config(str(cfg), res, err)
+    # the reference writes the "Results:" header before reading anything (:571-574)
+    assert open(res).read().startswith("Results: ")
