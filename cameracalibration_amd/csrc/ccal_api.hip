@@ -782,7 +782,7 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
                        cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
-                       org[2], ctx->psum_buf.as<double>());
+                       org[2], InlierMask{{0, 0, 0, 0, 1}, -1.0}, ctx->psum_buf.as<double>());
     hipLaunchKernelGGL(moments_finalize_kernel, dim3(kMoments), dim3(64), 0, ctx->stream,
                        ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
@@ -804,3 +804,5 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     plane_out[3] = (float)(c / len);
     return CCAL_OK;
 }
+
+#include "ransac_impl.hpp"

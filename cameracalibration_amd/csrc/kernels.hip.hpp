@@ -552,17 +552,23 @@ __global__ __launch_bounds__(64) void exact_max_kernel(const double* __restrict_
     if (threadIdx.x == 0) out_max[k * n_clouds + j] = m;
 }
 
-// Moments of the base-frame points q = float(M p) for the z-regression plane fit
-// (src/camera_calibration_optimization.cpp:100-119 on the cloud of :240-272).
-// Accumulated about a fixed origin `org` (the host passes an approximate
-// centroid) so the normal equations stay well conditioned in FP64.
-// Order of the 9 sums: 1, x, y, z, xx, xy, yy, xz, yz.
-constexpr int kMoments = 9;
+// Moments of the base-frame points q = float(M p): for the z-regression plane fit
+// (src/camera_calibration_optimization.cpp:100-119 on the cloud of :240-272) and,
+// with an inlier mask, for the RANSAC refit.  Accumulated about a fixed origin
+// `org` (an approximate centroid) so the normal equations / covariance stay well
+// conditioned in FP64.  Order of the 10 sums: 1, x, y, z, xx, xy, yy, xz, yz, zz.
+// mask: plane (a,b,c,d,|n|) and threshold; thr < 0 keeps every point.
+constexpr int kMoments = 10;
+
+struct InlierMask {
+    double pl[5];
+    double thr;
+};
 
 __global__ __launch_bounds__(256) void moments_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const BlockDesc* __restrict__ blocks, const double* __restrict__ mats, double ox, double oy,
-    double oz, double* __restrict__ part)
+    double oz, InlierMask mask, double* __restrict__ part)
 {
     __shared__ double sM[12];
     __shared__ double red[4][kMoments];
@@ -583,9 +589,14 @@ __global__ __launch_bounds__(256) void moments_kernel(
             p = zd * sM[r * 4 + 2] + p;
             q[r] = (float)p;
         }
+        if (mask.thr >= 0.0) {
+            const double num = mask.pl[0] * (double)q[0] + mask.pl[1] * (double)q[1] +
+                               mask.pl[2] * (double)q[2] + mask.pl[3];
+            if (!(__builtin_fabs(num) / mask.pl[4] < mask.thr)) continue;
+        }
         const double x = (double)q[0] - ox, y = (double)q[1] - oy, z = (double)q[2] - oz;
         m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
-        m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z;
+        m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z; m[9] += z * z;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -610,6 +621,132 @@ __global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __re
     for (int b = threadIdx.x; b < n_blocks; b += 64) s += part[(int64_t)b * kMoments + k];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (threadIdx.x == 0) out[k] = s;
+}
+
+// ---------------------------------------------------------------------------
+// RANSAC plane hypotheses
+// ---------------------------------------------------------------------------
+// Counter-based generator: splitmix64 of (seed + counter).
+__host__ __device__ inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Hypothesis h samples three distinct global point indices
+//   i_k = splitmix64(seed + 3h + k) mod N   (a repeat is bumped to the next index),
+// carries them to the base frame with the reference's transform arithmetic and
+// spans the plane: n = (q1-q0) x (q2-q0) normalised with n.z >= 0, d = -n.q0.
+// planes[h] = (a,b,c,d,|n|,valid).
+constexpr int kHypStride = 8;
+
+__global__ __launch_bounds__(256) void ransac_hyp_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const int64_t* __restrict__ cloud_pt_off, int n_clouds, int64_t total_pts,
+    const double* __restrict__ mats, uint64_t seed, int n_hyp, double* __restrict__ planes)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hyp) return;
+    int64_t idx[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t v = (int64_t)(splitmix64(seed + 3ull * (uint64_t)h + (uint64_t)k) % (uint64_t)total_pts);
+        for (int t = 0; t < k; ++t)
+            if (v == idx[t]) { v = (v + 1) % total_pts; t = -1; }
+        idx[k] = v;
+    }
+    double q[3][3];
+    for (int k = 0; k < 3; ++k) {
+        int j = 0;
+        while (j + 1 < n_clouds && idx[k] >= cloud_pt_off[j + 1]) ++j;
+        const double* M = mats + 12 * j;
+        const double xd = (double)xs[idx[k]], yd = (double)ys[idx[k]], zd = (double)zs[idx[k]];
+        for (int r = 0; r < 3; ++r) {
+            double p = M[r * 4 + 3];
+            p = xd * M[r * 4 + 0] + p;
+            p = yd * M[r * 4 + 1] + p;
+            p = zd * M[r * 4 + 2] + p;
+            q[k][r] = (double)(float)p;
+        }
+    }
+    const double u[3] = {q[1][0] - q[0][0], q[1][1] - q[0][1], q[1][2] - q[0][2]};
+    const double v[3] = {q[2][0] - q[0][0], q[2][1] - q[0][1], q[2][2] - q[0][2]};
+    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    double* out = planes + (int64_t)h * kHypStride;
+    if (!(len > 1e-12)) {
+        for (int e = 0; e < kHypStride; ++e) out[e] = 0.0;   // collinear sample: invalid
+        out[4] = 1.0;
+        return;
+    }
+    if (n[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len;
+    out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+    out[3] = -(n[0] * q[0][0] + n[1] * q[0][1] + n[2] * q[0][2]);
+    out[4] = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    out[5] = 1.0;
+    out[6] = 0.0; out[7] = 0.0;
+}
+
+// Folded 4-vectors of every (hypothesis, cloud) for the fixed pose matrices.
+__global__ __launch_bounds__(256) void wgen_planes_kernel(const double* __restrict__ planes,
+                                                          int n_hyp, int n_ctiles, int n_clouds,
+                                                          const double* __restrict__ mats,
+                                                          const double* __restrict__ centres,
+                                                          float* __restrict__ W)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)n_ctiles * kTilePoints) return;
+    const bool valid = c < n_hyp && planes[c * kHypStride + 5] != 0.0;
+    double n[3] = {0, 0, 0}, d = 0, inv = 1;
+    if (valid) {
+        const double* pl = planes + c * kHypStride;
+        n[0] = pl[0]; n[1] = pl[1]; n[2] = pl[2]; d = pl[3];
+        inv = 1.0 / pl[4];
+    }
+    const int64_t tile = c >> 4;
+    const int col = (int)(c & 15);
+    for (int j = 0; j < n_clouds; ++j) {
+        double w[4] = {0, 0, 0, 0};
+        if (valid) fold_plane(mats + 12 * j, n, d, inv, centres + 3 * j, w);
+        float* dst = W + ((int64_t)j * n_ctiles + tile) * 64 + col;
+        dst[0] = (float)w[0];
+        dst[16] = (float)w[1];
+        dst[32] = (float)w[2];
+        dst[48] = (float)w[3];
+    }
+}
+
+// Exact inlier counts for PB hypotheses (reference-arithmetic distance < thr).
+template <int PB>
+__global__ __launch_bounds__(256) void exact_count_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
+    const double* __restrict__ planes /* PB x kPlaneStride */, double thr,
+    unsigned long long* __restrict__ counts)
+{
+    __shared__ double sM[12];
+    __shared__ double sP[PB * kPlaneStride];
+    const BlockDesc bd = blocks[blockIdx.x];
+    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+    for (int i = threadIdx.x; i < PB * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
+    __syncthreads();
+    unsigned int cnt[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) cnt[k] = 0;
+    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            cnt[k] += exact_distance(sM, sP + k * kPlaneStride, x, y, z) < thr ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+        unsigned int c = cnt[k];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+    }
 }
 
 } // namespace ccal

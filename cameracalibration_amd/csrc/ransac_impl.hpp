@@ -1,0 +1,210 @@
+// ransac_impl.hpp -- batched RANSAC plane fit (included at the end of ccal_api.hip).
+//
+// Parameters follow the one RANSAC call in the reference tree, getPlane at
+// src/cloud_analyzer.cpp:103-121 (SACMODEL_PLANE, SAC_RANSAC, distance threshold
+// 0.01, setOptimizeCoefficients(true)); PCL itself is not part of that tree, so
+// the sampling scheme below is this library's own definition:
+//   1. n_hyp three-point hypotheses from a counter-based generator (kernel),
+//   2. every hypothesis scored against every point in ONE pass of the fast
+//      matrix-core contraction (|w.p| < thr counted instead of summed),
+//   3. the leaders of that count re-counted with the reference-arithmetic
+//      distance; most inliers wins, lowest hypothesis index on ties,
+//   4. winner refitted on its inliers: centroid + smallest-eigenvalue
+//      eigenvector of their covariance (what PCL's coefficient optimisation does).
+#pragma once
+
+namespace {
+
+// Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (FP64).
+void jacobi3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+template <int PB>
+void launch_exact_count(ccal_ctx* ctx, const CloudSet& cs, double thr)
+{
+    hipLaunchKernelGGL(exact_count_kernel<PB>, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), thr,
+                       ctx->count_buf.as<unsigned long long>());
+}
+
+constexpr int kRecount = 16;  // hypotheses re-counted exactly per pass
+
+} // namespace
+
+extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6], int n_hyp,
+                                 float threshold, uint64_t seed, float plane_out[4],
+                                 int64_t* inliers_out)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!pose || !plane_out || n_hyp <= 0 || !(threshold > 0.f))
+        return fail(ctx, CCAL_ERR_ARG, "ransac_plane: bad argument");
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+    if (cs.total_pts < 3) return fail(ctx, CCAL_ERR_ARG, "ransac_plane: fewer than three points");
+
+    std::vector<double> mats((size_t)C * 12);
+    pose_matrices(cs, pose, mats.data());
+    CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
+
+    // 1. hypotheses
+    CCAL_HIP(ctx, ctx->rec_buf.ensure((size_t)n_hyp * kHypStride * sizeof(double)));
+    hipLaunchKernelGGL(ransac_hyp_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.cloud_pt_off_dev.as<int64_t>(), C, (int64_t)cs.total_pts,
+                       ctx->mats_buf.as<double>(), seed, n_hyp, ctx->rec_buf.as<double>());
+
+    // 2. fast scoring of every (hypothesis, point) pair
+    FastLaunch f = plan_fast(ctx, cs, n_hyp);
+    CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)C * f.n_ctiles * 64 * sizeof(float)));
+    CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)f.n_splits * f.n_padded * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_hyp * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(wgen_planes_kernel, dim3((unsigned)((f.n_padded + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->rec_buf.as<double>(), n_hyp, f.n_ctiles, C,
+                       ctx->mats_buf.as<double>(), cs.centres_dev.as<double>(),
+                       ctx->w_buf.as<float>());
+    hipLaunchKernelGGL(inlier_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
+                       dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(), cs.groups.as<f32x4>(),
+                       cs.group_off_dev.as<int>(), ctx->partial_buf.as<unsigned long long>(),
+                       threshold, C, f.n_ctiles, f.n_splits);
+    hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
+                       ctx->stream, ctx->partial_buf.as<unsigned long long>(), f.n_padded,
+                       f.n_splits, (int64_t)n_hyp, ctx->cost_buf.as<unsigned long long>());
+    CCAL_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> fast(n_hyp);
+    std::vector<double> planes((size_t)n_hyp * kHypStride);
+    CCAL_HIP(ctx, hipMemcpyAsync(fast.data(), ctx->cost_buf.p, fast.size() * sizeof(unsigned long long),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipMemcpyAsync(planes.data(), ctx->rec_buf.p, planes.size() * sizeof(double),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // zero padding points have residual 0 and were counted for every hypothesis;
+    // invalid (collinear) hypotheses have w = 0 and count everything: drop them
+    std::vector<int> order;
+    unsigned long long best_fast = 0;
+    for (int h = 0; h < n_hyp; ++h) {
+        if (planes[(size_t)h * kHypStride + 5] == 0.0) continue;
+        fast[h] -= (unsigned long long)cs.n_pad_points;
+        best_fast = std::max(best_fast, fast[h]);
+        order.push_back(h);
+    }
+    if (order.empty()) return fail(ctx, CCAL_ERR_ARG, "ransac_plane: every sample was collinear");
+
+    // 3. exact recount of the leaders: FP32 scoring can misplace points that sit
+    // within rounding of the threshold, so everything within a small count margin
+    // of the fast maximum is re-counted with the reference arithmetic
+    const unsigned long long margin = std::max<unsigned long long>(8, (unsigned long long)(cs.total_pts / 4096));
+    std::vector<int> leaders;
+    for (int h : order)
+        if (fast[h] + margin >= best_fast) leaders.push_back(h);
+    int best_h = -1;
+    unsigned long long best_cnt = 0;
+    std::vector<double> pl((size_t)kRecount * kPlaneStride);
+    std::vector<unsigned long long> cnt(kRecount);
+    for (size_t l0 = 0; l0 < leaders.size(); l0 += kRecount) {
+        const int nb = (int)std::min<size_t>(kRecount, leaders.size() - l0);
+        for (int k = 0; k < kRecount; ++k) {
+            const int h = leaders[l0 + (k < nb ? k : 0)];
+            for (int e = 0; e < 5; ++e) pl[(size_t)k * kPlaneStride + e] = planes[(size_t)h * kHypStride + e];
+        }
+        CCAL_HIP(ctx, ctx->planes_buf.ensure(pl.size() * sizeof(double)));
+        CCAL_HIP(ctx, ctx->count_buf.ensure(kRecount * sizeof(unsigned long long)));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl.data(), pl.size() * sizeof(double),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, kRecount * sizeof(unsigned long long), ctx->stream));
+        launch_exact_count<kRecount>(ctx, cs, (double)threshold);
+        CCAL_HIP(ctx, hipGetLastError());
+        CCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->count_buf.p, kRecount * sizeof(unsigned long long),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nb; ++k) {
+            const int h = leaders[l0 + k];
+            if (best_h < 0 || cnt[k] > best_cnt || (cnt[k] == best_cnt && h < best_h)) {
+                best_cnt = cnt[k];
+                best_h = h;
+            }
+        }
+    }
+
+    // 4. refit on the winner's inliers
+    const double* bp = &planes[(size_t)best_h * kHypStride];
+    InlierMask mask;
+    for (int e = 0; e < 5; ++e) mask.pl[e] = bp[e];
+    mask.thr = (double)threshold;
+    double org[3];
+    for (int r = 0; r < 3; ++r)
+        org[r] = mats[r * 4 + 0] * cs.centres[0] + mats[r * 4 + 1] * cs.centres[1] +
+                 mats[r * 4 + 2] * cs.centres[2] + mats[r * 4 + 3];
+    CCAL_HIP(ctx, ctx->psum_buf.ensure((size_t)cs.n_blocks * kMoments * sizeof(double)));
+    CCAL_HIP(ctx, ctx->osum_buf.ensure(kMoments * sizeof(double)));
+    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
+                       org[2], mask, ctx->psum_buf.as<double>());
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(kMoments), dim3(64), 0, ctx->stream,
+                       ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
+    CCAL_HIP(ctx, hipGetLastError());
+    double m[kMoments];
+    CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double n[3] = {bp[0], bp[1], bp[2]}, d = bp[3];
+    if (m[0] >= 3.0) {
+        const double N = m[0];
+        const double cx = m[1] / N, cy = m[2] / N, cz = m[3] / N;
+        double A[3][3] = {{m[4] / N - cx * cx, m[5] / N - cx * cy, m[7] / N - cx * cz},
+                          {m[5] / N - cx * cy, m[6] / N - cy * cy, m[8] / N - cy * cz},
+                          {m[7] / N - cx * cz, m[8] / N - cy * cz, m[9] / N - cz * cz}};
+        double V[3][3];
+        jacobi3(A, V);
+        int k = 0;
+        if (A[1][1] < A[k][k]) k = 1;
+        if (A[2][2] < A[k][k]) k = 2;
+        double e[3] = {V[0][k], V[1][k], V[2][k]};
+        const double len = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        if (len > 0) {
+            const double sgn = e[2] < 0 ? -1.0 : 1.0;
+            for (int i = 0; i < 3; ++i) n[i] = sgn * e[i] / len;
+            d = -(n[0] * (cx + org[0]) + n[1] * (cy + org[1]) + n[2] * (cz + org[2]));
+        }
+    }
+    plane_out[0] = (float)n[0];
+    plane_out[1] = (float)n[1];
+    plane_out[2] = (float)n[2];
+    plane_out[3] = (float)d;
+    if (inliers_out) *inliers_out = (int64_t)best_cnt;
+    return CCAL_OK;
+}

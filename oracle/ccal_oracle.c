@@ -577,3 +577,145 @@ int orc_file_id(const char* filename)
     if (us2) *us2 = 0;
     return atoi(f);
 }
+
+/* ------------------------------------------------------------------ */
+/* RANSAC plane                                                        */
+/* ------------------------------------------------------------------ */
+
+/* The reference never calls its RANSAC helper (cloud_analyzer.cpp:103-121 is not
+ * built) and PCL is not in its tree, so there is nothing to restate line by
+ * line: this is the CPU statement of the library's own sampling scheme, scored
+ * with the reference's distance arithmetic (:121-124) on q = float(M p).
+ * Parity unpinned. */
+static uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+static void jacobi3(double A[3][3], double V[3][3])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
+                      uint64_t seed, float plane_out[4], int64_t* inliers_out, int* best_hyp_out)
+{
+    int C = s->n_clouds;
+    double* M = (double*)malloc((size_t)C * 16 * sizeof(double));
+    int64_t* off = (int64_t*)malloc((size_t)(C + 1) * sizeof(int64_t));
+    off[0] = 0;
+    for (int j = 0; j < C; ++j) {
+        cloud_matrix(s, j, pose, M + 16 * j);
+        off[j + 1] = off[j] + (int64_t)s->n_pts[j];
+    }
+    int64_t total = off[C];
+    float* q = (float*)malloc((size_t)total * 3 * sizeof(float));
+    for (int j = 0; j < C; ++j)
+        for (size_t i = 0; i < s->n_pts[j]; ++i)
+            orc_transform_point(M + 16 * j, s->xyz[j] + 3 * i, q + 3 * (off[j] + (int64_t)i));
+
+    int best_h = -1;
+    int64_t best_cnt = -1;
+    double best_pl[5] = {0, 0, 0, 0, 1};
+    for (int h = 0; h < n_hyp; ++h) {
+        int64_t idx[3];
+        for (int k = 0; k < 3; ++k) {
+            int64_t v = (int64_t)(splitmix64(seed + 3ull * (uint64_t)h + (uint64_t)k) % (uint64_t)total);
+            for (int t = 0; t < k; ++t)
+                if (v == idx[t]) { v = (v + 1) % total; t = -1; }
+            idx[k] = v;
+        }
+        double p[3][3];
+        for (int k = 0; k < 3; ++k)
+            for (int r = 0; r < 3; ++r) p[k][r] = (double)q[3 * idx[k] + r];
+        double u[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+        double v[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+        double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!(len > 1e-12)) continue;
+        if (n[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len;
+        double pl[5];
+        pl[0] = n[0]; pl[1] = n[1]; pl[2] = n[2];
+        pl[3] = -(n[0] * p[0][0] + n[1] * p[0][1] + n[2] * p[0][2]);
+        pl[4] = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < total; ++i) {
+            double num = pl[0] * (double)q[3 * i] + pl[1] * (double)q[3 * i + 1] + pl[2] * (double)q[3 * i + 2] + pl[3];
+            if (fabs(num) / pl[4] < (double)threshold) ++cnt;
+        }
+        if (cnt > best_cnt) { best_cnt = cnt; best_h = h; memcpy(best_pl, pl, sizeof pl); }
+    }
+    double n[3] = {best_pl[0], best_pl[1], best_pl[2]}, d = best_pl[3];
+    if (best_h >= 0) {
+        /* origin as the library uses: first cloud's centre carried to the base frame */
+        double c0[3] = {0, 0, 0};
+        for (size_t i = 0; i < s->n_pts[0]; ++i)
+            for (int k = 0; k < 3; ++k) c0[k] += s->xyz[0][3 * i + k];
+        for (int k = 0; k < 3; ++k) c0[k] /= (double)s->n_pts[0];
+        double org[3];
+        for (int r = 0; r < 3; ++r)
+            org[r] = M[r * 4 + 0] * c0[0] + M[r * 4 + 1] * c0[1] + M[r * 4 + 2] * c0[2] + M[r * 4 + 3];
+        double m[10] = {0};
+        for (int64_t i = 0; i < total; ++i) {
+            double num = best_pl[0] * (double)q[3 * i] + best_pl[1] * (double)q[3 * i + 1] +
+                         best_pl[2] * (double)q[3 * i + 2] + best_pl[3];
+            if (!(fabs(num) / best_pl[4] < (double)threshold)) continue;
+            double x = (double)q[3 * i] - org[0], y = (double)q[3 * i + 1] - org[1], z = (double)q[3 * i + 2] - org[2];
+            m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+            m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z; m[9] += z * z;
+        }
+        if (m[0] >= 3.0) {
+            double N = m[0], cx = m[1] / N, cy = m[2] / N, cz = m[3] / N;
+            double A[3][3] = {{m[4] / N - cx * cx, m[5] / N - cx * cy, m[7] / N - cx * cz},
+                              {m[5] / N - cx * cy, m[6] / N - cy * cy, m[8] / N - cy * cz},
+                              {m[7] / N - cx * cz, m[8] / N - cy * cz, m[9] / N - cz * cz}};
+            double V[3][3];
+            jacobi3(A, V);
+            int k = 0;
+            if (A[1][1] < A[k][k]) k = 1;
+            if (A[2][2] < A[k][k]) k = 2;
+            double e[3] = {V[0][k], V[1][k], V[2][k]};
+            double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            if (len > 0) {
+                double sgn = e[2] < 0 ? -1.0 : 1.0;
+                for (int i = 0; i < 3; ++i) n[i] = sgn * e[i] / len;
+                d = -(n[0] * (cx + org[0]) + n[1] * (cy + org[1]) + n[2] * (cz + org[2]));
+            }
+        }
+    }
+    plane_out[0] = (float)n[0]; plane_out[1] = (float)n[1]; plane_out[2] = (float)n[2]; plane_out[3] = (float)d;
+    if (inliers_out) *inliers_out = best_cnt;
+    if (best_hyp_out) *best_hyp_out = best_h;
+    free(q); free(off); free(M);
+}

@@ -123,6 +123,12 @@ void orc_gd_default_opts(orc_gd_opts* o);
 void orc_gd_minimize(const orc_scene* s, const float plane[4], int dim, const double* x0,
                      const orc_gd_opts* o, orc_gd_result* r);
 
+/* CPU statement of the library's RANSAC scheme (three-point hypotheses from
+ * splitmix64(seed+3h+k), exact-arithmetic inlier count, lowest index on ties,
+ * covariance refit).  Not a reference restatement: see ccal_oracle.c. */
+void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
+                      uint64_t seed, float plane_out[4], int64_t* inliers_out, int* best_hyp_out);
+
 /* stof-based parsers: camera_calibration_optimization.cpp:70-98, helpers.cpp:238-259 */
 int orc_parse_pose_csv(const char* line, double scale, int angle_is_degree, double pose[6]);
 int orc_file_id(const char* filename); /* :131-146 */

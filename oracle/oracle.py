@@ -113,6 +113,8 @@ def lib() -> C.CDLL:
         L.orc_gd_minimize.argtypes = [
             C.POINTER(Scene), _F, C.c_int, _D, C.POINTER(GdOpts), C.POINTER(GdResult),
         ]
+        L.orc_ransac_plane.argtypes = [C.POINTER(Scene), _D, C.c_int, C.c_float, C.c_uint64, _F,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]
         L.orc_parse_pose_csv.restype = C.c_int
         L.orc_parse_pose_csv.argtypes = [C.c_char_p, C.c_double, C.c_int, _D]
         L.orc_file_id.restype = C.c_int
@@ -184,6 +186,15 @@ class OracleScene:
         out = np.empty((total, 3), dtype=np.float32)
         n = lib().orc_combined_cloud(C.byref(self.c), _d(p), _f(out))
         return out[:n]
+
+    def ransac_plane(self, pose, n_hyp: int, threshold: float, seed: int):
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        out = np.empty(4, dtype=np.float32)
+        inl = C.c_int64(0)
+        best = C.c_int(-1)
+        lib().orc_ransac_plane(C.byref(self.c), _d(p), int(n_hyp), float(threshold), int(seed), _f(out),
+                               C.byref(inl), C.byref(best))
+        return out, int(inl.value), int(best.value)
 
     def gd_minimize(self, plane, x0, opts: Optional[GdOpts] = None) -> GdResult:
         pl = np.ascontiguousarray(plane, dtype=np.float32)

@@ -172,6 +172,30 @@ def test_fit_plane_matches_oracle(gpu_opt, oracle, calib1):
     np.testing.assert_allclose(got, want, rtol=0, atol=1.5e-8)
 
 
+@pytest.mark.parametrize("outliers", [0.0, 0.3])
+def test_ransac_plane_matches_oracle(gpu_opt, oracle, outliers):
+    s = make_scene(5, 6000, seed=31, ragged=True, noise=0.002)
+    rng = np.random.default_rng(9)
+    clouds = []
+    for c in s.clouds:
+        c = c.copy()
+        k = int(outliers * len(c))
+        if k:
+            c[rng.choice(len(c), k, replace=False), 2] += rng.uniform(0.02, 0.2, k).astype(np.float32)
+        clouds.append(c)
+    gpu_opt.upload_clouds(1, clouds, s.base_T_flange)
+    o = oracle.OracleScene(clouds, s.base_T_flange)
+    for n_hyp, seed in ((64, 1), (500, 12345)):
+        want, want_inl, _ = o.ransac_plane(s.pose_true, n_hyp, 0.004, seed)
+        got, got_inl = gpu_opt.ransac_plane(s.pose_true, n_hyp, 0.004, seed, which=1)
+        assert got_inl == want_inl                       # integer count: identical
+        # same winner, same inlier set; refit moments summed in a different order
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+        assert abs(np.linalg.norm(got[:3]) - 1) < 1e-6 and got[2] > 0
+        # the recovered plane is the scene's plane
+        np.testing.assert_allclose(got, s.plane, atol=2e-3)
+
+
 def test_gradient_descent_matches_oracle(gpu_opt, oracle, calib1):
     ds = [calib1["ds_%d" % i] for i in range(4)]
     gpu_opt.upload_clouds(0, ds, calib1["base_T_flange"])
