@@ -93,21 +93,15 @@ def main():
     grid = cc.Grid.make([-20] * 3 + [-5] * 3, [steps_mm] * 3 + [steps_deg] * 3, counts)
     total = grid.size
     per_rank = total // world
-    begin, end = rank * per_rank, (rank + 1) * per_rank if rank < world - 1 else total
+    begin, end = rank * per_rank, (rank + 1) * per_rank      # total = world * per_rank exactly
 
-    gather_in = torch.zeros(2, dtype=torch.float64, device="cuda")
-    gather_out = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+    from cameracalibration_amd.distributed import merge_argmin
 
     def step():
         idx, cost, pose, st = opt.grid_search(scene.pose_init, grid, begin, end)
         if world > 1:
-            # the one exchange of the path: (cost, index) records, lexicographic min
-            gather_in[0] = cost
-            gather_in[1] = float(idx)          # indices < 2^53 are exact in f64
-            dist.all_gather(gather_out, gather_in)
-            recs = torch.stack(gather_out).cpu().numpy()
-            w = cc.binding.argmin_merge(recs[:, 0], recs[:, 1].astype(np.int64))
-            idx, cost = int(recs[w, 1]), float(recs[w, 0])
+            # the one exchange of the path: (cost, index) records over RCCL, lexicographic min
+            cost, idx, _ = merge_argmin(cost, idx, device=torch.device("cuda", local_rank))
             pose = cc.grid_pose(grid, scene.pose_init, idx)
         return idx, cost, pose, st
 
