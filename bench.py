@@ -37,6 +37,20 @@ PEAK_FP32_TFLOPS = 157.3          # MI355X FP32 vector == FP32-input MFMA peak
 FLOP_PER_RESIDUAL = 8             # 4 mul + 3 add (K=4 dot) + 1 add into the running sum
 
 
+def hbm_traffic_per_launch(args):
+    """HBM bytes per launch of the residual kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, plus WRITE_SIZE).
+    Counters are collected offline (tools/profile_r1.sh), so the figure is only quoted
+    for the workload it was measured on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_residual_kernel.json")
+    if not os.path.exists(path) or (args.clouds, args.points, args.axis) != (20, 300_000, 10):
+        return None
+    try:
+        return json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,10 +84,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CCAL_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs
+    # than ranks (ranks then share devices); the real runs use RCCL ("nccl").
+    backend = os.environ.get("CCAL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    xdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -82,7 +104,7 @@ def main():
 
     # --- inputs: identical scene on every rank (seeded), resident before timing ----
     scene = make_scene(args.clouds, args.points)
-    opt = cc.Optimizer(local_rank)
+    opt = cc.Optimizer(dev_index)
     opt.upload_clouds(cc.CCAL_DOWNSAMPLED, scene.clouds, scene.base_T_flange)
     opt.set_plane(scene.plane)
 
@@ -101,7 +123,7 @@ def main():
         idx, cost, pose, st = opt.grid_search(scene.pose_init, grid, begin, end)
         if world > 1:
             # the one exchange of the path: (cost, index) records over RCCL, lexicographic min
-            cost, idx, _ = merge_argmin(cost, idx, device=torch.device("cuda", local_rank))
+            cost, idx, _ = merge_argmin(cost, idx, device=xdev)
             pose = cc.grid_pose(grid, scene.pose_init, idx)
         return idx, cost, pose, st
 
@@ -120,7 +142,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -157,7 +179,7 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach_tflops / PEAK_FP32_TFLOPS,
-            "traffic": None,
+            "traffic": hbm_traffic_per_launch(args),
             "kernel": "residual_mfma_kernel",
             "kernel_avg_ms": kernel_ms / max(launches, 1),
             "flop_per_residual": FLOP_PER_RESIDUAL,
