@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--axis", type=int, default=10, help="grid steps per axis (10 -> 10^6 candidates)")
     ap.add_argument("--cpu-candidates", type=int, default=48,
                     help="candidates of the workload scored by the CPU oracle for cpu_baseline (0 = skip)")
-    ap.add_argument("--gd-iterations", type=int, default=20,
+    ap.add_argument("--gd-iterations", type=int, default=-1,
                     help="iteration cap of the untimed GD refinement (-1 = reference's 10000, 0 = skip)")
     return ap.parse_args()
 

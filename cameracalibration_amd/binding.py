@@ -135,6 +135,7 @@ SIGNATURES = {
     "ccal_get_plane": (C.c_int, [_CTX, _F]),
     "ccal_eval": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, _D, _D]),
     "ccal_eval_fast": (C.c_int, [_CTX, C.c_int, C.c_int64, _D, _F]),
+    "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
     "ccal_grid_size": (C.c_int64, [_P(Grid)]),
     "ccal_grid_pose": (None, [_P(Grid), _D, C.c_int64, _D]),
@@ -291,6 +292,13 @@ class Optimizer:
             self._lib.ccal_eval(self._ctx, which, 1, _dptr(P), None, _dptr(cost), _dptr(mean), _dptr(mx))
         )
         return float(cost[0]), mean, mx
+
+    def ordered_sum(self, values) -> float:
+        """((0 + v0) + v1) + ... with a rounding after every add, evaluated on the GPU."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        out = C.c_double(0.0)
+        self._check(self._lib.ccal_ordered_sum(self._ctx, _dptr(v), v.size, C.byref(out)))
+        return float(out.value)
 
     def get_error_fast(self, poses, which: int = CCAL_DOWNSAMPLED) -> np.ndarray:
         P = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)

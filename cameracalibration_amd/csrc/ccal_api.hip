@@ -64,38 +64,6 @@ void pose_matrices(const CloudSet& cs, const double pose[6], double* mats)
         compose_rows(cs.base_T_flange.data() + 16 * j, R, pose, mats + 12 * j);
 }
 
-template <int PB>
-void launch_exact(ccal_ctx* ctx, const CloudSet& cs)
-{
-    hipLaunchKernelGGL(exact_dist_kernel<PB>, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
-                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
-                       ctx->planes_buf.as<double>(), cs.n_clouds, (int64_t)cs.total_pts,
-                       ctx->dist_buf.as<double>(), ctx->pmax_buf.as<double>());
-}
-
-int pick_pb(int n)
-{
-    static const int sizes[] = {1, 2, 4, 8, 13, 16, 21, 32};
-    for (int s : sizes)
-        if (n <= s) return s;
-    return 32;
-}
-
-void dispatch_exact(ccal_ctx* ctx, const CloudSet& cs, int pb)
-{
-    switch (pb) {
-    case 1: launch_exact<1>(ctx, cs); break;
-    case 2: launch_exact<2>(ctx, cs); break;
-    case 4: launch_exact<4>(ctx, cs); break;
-    case 8: launch_exact<8>(ctx, cs); break;
-    case 13: launch_exact<13>(ctx, cs); break;
-    case 16: launch_exact<16>(ctx, cs); break;
-    case 21: launch_exact<21>(ctx, cs); break;
-    default: launch_exact<32>(ctx, cs); break;
-    }
-}
-
 // Splits of the point stream so that the launch has enough blocks to fill the
 // chip several times over, without cutting a cloud into slivers.
 int choose_splits(const ccal_ctx* ctx, const CloudSet& cs, int64_t cand_blocks)
@@ -432,15 +400,15 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
 
     // poses per pass: bounded by the distance buffer (8 B per pose and point)
     const int64_t dist_budget = (int64_t)8 << 30;
-    int max_batch = (int)std::min<int64_t>(32, std::max<int64_t>(1, dist_budget / (8 * (int64_t)cs.total_pts)));
+    int max_batch = (int)std::min<int64_t>(kMaxPosesPerPass, std::max<int64_t>(1, dist_budget / (8 * (int64_t)cs.total_pts)));
     std::vector<double> mats, planes, hsum, hmax;
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
         const int nb = std::min(max_batch, n_poses - k0);
-        const int pb = pick_pb(nb);
+        const int pb = nb;
         mats.assign((size_t)pb * C * 12, 0.0);
         planes.assign((size_t)pb * kPlaneStride, 0.0);
         for (int k = 0; k < pb; ++k) {
-            const int src = k0 + (k < nb ? k : 0);  // padding slots repeat the first pose
+            const int src = k0 + k;
             pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data() + (size_t)k * C * 12);
             double* pl = planes.data() + (size_t)k * kPlaneStride;
             if (planes4) {
@@ -454,7 +422,6 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
         CCAL_HIP(ctx, ctx->planes_buf.ensure(planes.size() * sizeof(double)));
         CCAL_HIP(ctx, ctx->dist_buf.ensure((size_t)pb * cs.total_pts * sizeof(double)));
-        CCAL_HIP(ctx, ctx->pmax_buf.ensure((size_t)cs.n_blocks * pb * sizeof(double)));
         CCAL_HIP(ctx, ctx->osum_buf.ensure((size_t)pb * C * sizeof(double)));
         CCAL_HIP(ctx, ctx->omax_buf.ensure((size_t)pb * C * sizeof(double)));
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
@@ -462,14 +429,16 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, planes.data(),
                                      planes.size() * sizeof(double), hipMemcpyHostToDevice,
                                      ctx->stream));
-        dispatch_exact(ctx, cs, pb);
+        hipLaunchKernelGGL(exact_dist_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                           cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                           cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
+                           ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
+                           ctx->dist_buf.as<double>());
         const int n_chains = pb * C;
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3((n_chains + 63) / 64), dim3(64), 0,
+        hipLaunchKernelGGL(ordered_sum_kernel, dim3(n_chains), dim3(64 * kChainWaves), 0,
                            ctx->stream, ctx->dist_buf.as<double>(),
                            cs.cloud_pt_off_dev.as<int64_t>(), n_chains, C,
-                           (int64_t)cs.total_pts, ctx->osum_buf.as<double>());
-        hipLaunchKernelGGL(exact_max_kernel, dim3(pb * C), dim3(64), 0, ctx->stream,
-                           ctx->pmax_buf.as<double>(), cs.cloud_block_off_dev.as<int>(), pb, C,
+                           (int64_t)cs.total_pts, ctx->osum_buf.as<double>(),
                            ctx->omax_buf.as<double>());
         CCAL_HIP(ctx, hipGetLastError());
         hsum.resize((size_t)pb * C);
@@ -499,6 +468,28 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 {
     return ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean,
                             per_cloud_max);
+}
+
+// The accumulation primitive of the exact path on a caller-supplied array (see ccal.h).
+extern "C" int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (!out || (n && !values)) return fail(ctx, CCAL_ERR_ARG, "ordered_sum: null argument");
+    if (int rc = bind(ctx)) return rc;
+    const int64_t off[2] = {0, (int64_t)n};
+    CCAL_HIP(ctx, ctx->dist_buf.ensure(std::max<size_t>(n, 1) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->tbl_buf.ensure(sizeof off));
+    CCAL_HIP(ctx, ctx->osum_buf.ensure(sizeof(double)));
+    CCAL_HIP(ctx, ctx->omax_buf.ensure(sizeof(double)));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->dist_buf.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64 * kChainWaves), 0, ctx->stream, ctx->dist_buf.as<double>(),
+                       ctx->tbl_buf.as<int64_t>(), 1, 1, (int64_t)n, ctx->osum_buf.as<double>(),
+                       ctx->omax_buf.as<double>());
+    CCAL_HIP(ctx, hipGetLastError());
+    CCAL_HIP(ctx, hipMemcpyAsync(out, ctx->osum_buf.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
 }
 
 // ---------------------------------------------------------------------------

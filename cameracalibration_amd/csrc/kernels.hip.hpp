@@ -450,106 +450,197 @@ __device__ inline double exact_distance(const double* M, const double* pl, float
     return __builtin_fabs(num) / pl[4];
 }
 
-// Distances of every point for PB poses: dist[k][i] (pose-major, i = global point
-// index) plus the per-block maximum.  The sums are NOT formed here: the
-// reference adds the distances of a cloud one by one in point order
+// Distances of every point for n_poses poses: dist[k][i] (pose-major, i = global
+// point index).  The sums are NOT formed here: the reference adds the distances
+// of a cloud one by one in point order
 // (src/camera_calibration_optimization.cpp:305), and floating-point addition is
-// not associative, so the ordered sum is a separate single-chain pass below.
-template <int PB>
+// not associative, so the ordered sum (and the maximum) is the separate chain
+// pass below.
+constexpr int kMaxPosesPerPass = 32;
+
 __global__ __launch_bounds__(256) void exact_dist_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
-    const double* __restrict__ planes, int n_clouds, int64_t total_pts,
-    double* __restrict__ dist, double* __restrict__ part_max)
+    const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
+    double* __restrict__ dist)
 {
-    __shared__ double sM[PB * 12];
-    __shared__ double sP[PB * kPlaneStride];
-    __shared__ double red_m[4][PB];
+    __shared__ double sM[kMaxPosesPerPass * 12];
+    __shared__ double sP[kMaxPosesPerPass * kPlaneStride];
     const BlockDesc bd = blocks[blockIdx.x];
-    for (int i = threadIdx.x; i < PB * 12; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n_poses * 12; i += blockDim.x) {
         int k = i / 12, e = i % 12;
         sM[i] = mats[((int64_t)k * n_clouds + bd.cloud) * 12 + e];
     }
-    for (int i = threadIdx.x; i < PB * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
+    for (int i = threadIdx.x; i < n_poses * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
     __syncthreads();
-
-    double mx[PB];
+    for (int64_t i0 = bd.begin + threadIdx.x; i0 < bd.end; i0 += 4 * blockDim.x) {
+        float x[4], y[4], z[4];
 #pragma unroll
-    for (int k = 0; k < PB; ++k) mx[k] = -1e9;  // :288 error_mx = -1e9
-
-    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
-        const float x = xs[i], y = ys[i], z = zs[i];
-#pragma unroll
-        for (int k = 0; k < PB; ++k) {
-            const double d = exact_distance(sM + k * 12, sP + k * kPlaneStride, x, y, z);
-            dist[(int64_t)k * total_pts + i] = d;
-            if (d > mx[k]) mx[k] = d;
+        for (int p = 0; p < 4; ++p) {
+            const int64_t i = i0 + (int64_t)p * blockDim.x;
+            const bool in = i < bd.end;
+            x[p] = in ? xs[i] : 0.f; y[p] = in ? ys[i] : 0.f; z[p] = in ? zs[i] : 0.f;
         }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int k = 0; k < n_poses; ++k) {
+            const double* M = sM + k * 12;
+            const double* pl = sP + k * kPlaneStride;
 #pragma unroll
-    for (int k = 0; k < PB; ++k) {
-        double m = mx[k];
-        for (int off = 32; off > 0; off >>= 1) {
-            double om = __shfl_xor(m, off, 64);
-            m = om > m ? om : m;
+            for (int p = 0; p < 4; ++p) {
+                const int64_t i = i0 + (int64_t)p * blockDim.x;
+                if (i < bd.end) dist[(int64_t)k * total_pts + i] = exact_distance(M, pl, x[p], y[p], z[p]);
+            }
         }
-        if (lane == 0) red_m[wave][k] = m;
-    }
-    __syncthreads();
-    if (threadIdx.x < PB) {
-        const int k = threadIdx.x;
-        double m = red_m[0][k];
-        for (int w = 1; w < 4; ++w) m = red_m[w][k] > m ? red_m[w][k] : m;
-        part_max[(int64_t)blockIdx.x * PB + k] = m;
     }
 }
 
-// One lane per (pose k, cloud j) chain: average = ((0 + d_0) + d_1) + ... in
-// point order, exactly the reference's accumulation.  64 chains advance per
-// wave instruction; each lane streams its own row of `dist`.
-__global__ __launch_bounds__(64) void ordered_sum_kernel(const double* __restrict__ dist,
-                                                         const int64_t* __restrict__ cloud_pt_off,
-                                                         int n_chains, int n_clouds,
-                                                         int64_t total_pts,
-                                                         double* __restrict__ out_sum)
+// Ordered sum of one (pose k, cloud j) chain: average = ((0 + d_0) + d_1) + ... in
+// point order with a rounding after every add, exactly the reference's
+// accumulation -- computed by one workgroup per chain as an exact parallel
+// emulation of the sequential sum:
+//
+//   While the running sum s stays inside one binade [2^e, 2^(e+1)) every add
+//   rounds to a multiple of u = 2^(e-52).  With S = s/u (an integer in
+//   [2^52, 2^53)) and t = d/u = q + r (q integer, 0 <= r < 1), round-to-nearest-
+//   even gives  S' = S + q + [r > 1/2]  and, only for an exact tie r == 1/2,
+//   S' = S + q + ((S + q) odd).  So an element is a map  parity(S) -> increment,
+//   and maps compose associatively:  (A then B)[p] = A[p] + B[(p + A[p]) & 1].
+//   Each lane folds 8 consecutive elements into its pair (inc[0], inc[1]), a
+//   wave composes its 64 pairs in lane order with a shuffle tree (one 512-element
+//   segment), and thread 0 applies the 16 segment maps of the workgroup in order
+//   to the actual S -- a segment is accepted iff S + total < 2^53, which (all
+//   increments being >= 0) holds exactly when no add inside it left the binade.
+//   The first rejected segment (about once per binade, ~20 times per chain) is
+//   replayed with plain one-by-one adds and the pass restarts behind it with the
+//   new binade; the first kChainWarm elements, where binades change every few
+//   adds, are summed one by one up front.
+//
+// Distances are >= 0 by construction.
+constexpr int kChainRun = 8;                       // consecutive elements per lane
+constexpr int kChainSeg = 64 * kChainRun;          // elements per wave segment
+constexpr int kChainWaves = 16;                    // segments per pass
+constexpr int kChainPass = kChainSeg * kChainWaves;
+
+__device__ inline void chain_fold(const double v[kChainRun], double scale, unsigned long long& inc0,
+                                  unsigned long long& inc1, bool& ok)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const double two53 = 9007199254740992.0;
+    inc0 = 0; inc1 = 0; ok = true;
+#pragma unroll
+    for (int t = 0; t < kChainRun; ++t) {
+        const double tt = v[t] * scale;             // exact (power of two)
+        ok = ok && (tt < two53);                    // also false for NaN
+        const double tc = tt < two53 ? tt : 0.0;
+        const unsigned long long q = (unsigned long long)tc;
+        const double r = tc - (double)q;            // exact
+        const unsigned long long up = r > 0.5 ? 1ull : 0ull;
+        const bool tie = r == 0.5;
+        inc0 += q + (tie ? ((inc0 + q) & 1ull) : up);
+        inc1 += q + (tie ? ((1ull + inc1 + q) & 1ull) : up);
+    }
+    // compose the 64 lane maps in lane order (left operand = lower lane)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long r0 = __shfl_down(inc0, off, 64);
+        const unsigned long long r1 = __shfl_down(inc1, off, 64);
+        inc0 += (inc0 & 1ull) ? r1 : r0;
+        inc1 += ((1ull + inc1) & 1ull) ? r1 : r0;
+    }
+    ok = __all(ok ? 1 : 0);
+}
+
+// Also returns the chain's maximum (:306-307; order-free).
+__global__ __launch_bounds__(64 * kChainWaves) void ordered_sum_kernel(
+    const double* __restrict__ dist, const int64_t* __restrict__ cloud_pt_off, int n_chains,
+    int n_clouds, int64_t total_pts, double* __restrict__ out_sum, double* __restrict__ out_max)
+{
+    __shared__ double sh_vals[kChainWaves][kChainSeg];   // this pass's elements (64 KiB)
+    __shared__ unsigned long long sh_inc[kChainWaves][2];
+    __shared__ int sh_ok[kChainWaves];
+    __shared__ double sh_red[kChainWaves];
+    __shared__ double sh_s;
+    __shared__ int sh_first;
+    const int c = blockIdx.x;
     if (c >= n_chains) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = c / n_clouds, j = c % n_clouds;
     const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
     const double* row = dist + (int64_t)k * total_pts;
-    double s = 0.0;
-    int64_t i = b;
-    for (; i + 8 <= e; i += 8) {
-        double v[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = row[i + t];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) s += v[t];
-    }
-    for (; i < e; ++i) s += row[i];
-    out_sum[c] = s;
-}
+    const int my = wave * kChainSeg + lane * kChainRun;   // this lane's offset inside a pass
 
-// One wave per (pose k, cloud j): maximum over the cloud's block maxima.
-__global__ __launch_bounds__(64) void exact_max_kernel(const double* __restrict__ part_max,
-                                                       const int* __restrict__ cloud_block_off,
-                                                       int PB, int n_clouds,
-                                                       double* __restrict__ out_max)
-{
-    const int k = blockIdx.x / n_clouds, j = blockIdx.x % n_clouds;
-    const int b0 = cloud_block_off[j], b1 = cloud_block_off[j + 1];
-    double m = -1e9;
-    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
-        double v = part_max[(int64_t)b * PB + k];
-        m = v > m ? v : m;
+    double s = 0.0, mx = -1e9;                            // :288 error_mx = -1e9
+    double v[kChainRun], vn[kChainRun];
+#pragma unroll
+    for (int t = 0; t < kChainRun; ++t) v[t] = b + my + t < e ? row[b + my + t] : 0.0;   // a zero adds nothing
+
+    for (int64_t i = b; i < e; i += kChainPass) {
+        const int64_t left = e - i;
+        const int nseg = left >= kChainPass ? kChainWaves : (int)((left + kChainSeg - 1) / kChainSeg);
+        // next pass in flight while this one is folded
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) {
+            const int64_t idx = i + kChainPass + my + t;
+            vn[t] = idx < e ? row[idx] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) {
+            sh_vals[wave][lane * kChainRun + t] = v[t];
+            if (i + my + t < e) mx = v[t] > mx ? v[t] : mx;
+        }
+        int first = 0;
+        for (;;) {
+            const unsigned long long sbits = (unsigned long long)__double_as_longlong(s);
+            const int ebiased = (int)((sbits >> 52) & 0x7ff);
+            const bool usable = ebiased >= 64 && ebiased <= 2000;
+            // scale = 1/u = 2^(52 - e): exponent field 1023 + 52 - (ebiased - 1023)
+            const double scale =
+                usable ? __longlong_as_double((long long)((unsigned long long)(2098 - ebiased) << 52)) : 1.0;
+            if (usable && wave >= first && wave < nseg) {
+                unsigned long long inc0, inc1;
+                bool ok;
+                chain_fold(v, scale, inc0, inc1, ok);
+                if (lane == 0) { sh_inc[wave][0] = inc0; sh_inc[wave][1] = inc1; sh_ok[wave] = ok ? 1 : 0; }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int adv = first;
+                double sn = s;
+                if (usable) {
+                    unsigned long long S = (unsigned long long)(s * scale);   // exact integer in [2^52, 2^53)
+                    for (; adv < nseg; ++adv) {
+                        const unsigned long long total = sh_inc[adv][S & 1ull];
+                        if (!sh_ok[adv] || total >= (1ull << 53) || S + total >= (1ull << 53)) break;
+                        S += total;
+                    }
+                    sn = (double)S / scale;                                  // exact
+                }
+                if (adv < nseg) {
+                    // the segment that left the binade (or s not yet usable): one by one
+                    for (int t = 0; t < kChainSeg; ++t) sn += sh_vals[adv][t];
+                    ++adv;
+                }
+                sh_s = sn;
+                sh_first = adv;
+            }
+            __syncthreads();
+            s = sh_s;
+            first = sh_first;
+            if (first >= nseg) break;
+        }
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) v[t] = vn[t];
+        __syncthreads();
     }
     for (int off = 32; off > 0; off >>= 1) {
-        double om = __shfl_xor(m, off, 64);
-        m = om > m ? om : m;
+        const double om = __shfl_xor(mx, off, 64);
+        mx = om > mx ? om : mx;
     }
-    if (threadIdx.x == 0) out_max[k * n_clouds + j] = m;
+    if (lane == 0) sh_red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kChainWaves; ++w) mx = sh_red[w] > mx ? sh_red[w] : mx;
+        out_sum[c] = s;
+        out_max[c] = mx;
+    }
 }
 
 // Moments of the base-frame points q = float(M p): for the z-regression plane fit

@@ -84,6 +84,12 @@ int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
               const double* planes4, double* cost,
               double* per_cloud_mean, double* per_cloud_max);
 
+/* The accumulation of :305 (`average += distance`, one rounding per add, in
+ * order) for n non-negative doubles, computed on the GPU by the same kernel
+ * ccal_eval uses: out = ((0 + v[0]) + v[1]) + ... bit for bit.  Exposed so the
+ * parallel emulation of the sequential sum can be validated on arbitrary data. */
+int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out);
+
 /* Same objective for a large batch of poses on the fast FP32 path (folded
  * 4-vector, matrix-core K=4 contraction).  Costs agree with ccal_eval to
  * ~1e-6 relative; used where thousands..millions of poses are scored.

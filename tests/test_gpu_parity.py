@@ -75,6 +75,46 @@ def test_exact_and_fast_vs_oracle(gpu_opt, oracle, n_clouds, n_points, ragged):
     np.testing.assert_array_equal(mx, omx)
 
 
+def _seq_sum(v):
+    s = np.float64(0.0)
+    for x in v:
+        s = s + x
+    return float(s)
+
+
+def test_ordered_sum_is_the_sequential_sum(gpu_opt):
+    """The wave-parallel emulation must reproduce every rounding of the one-by-one
+    sum: exact ties (values on half-ulp boundaries), binade crossings, zeros,
+    wide dynamic range, lengths around the 512-element step."""
+    rng = np.random.default_rng(17)
+    cases = []
+    for n in (0, 1, 2, 511, 512, 513, 1024, 5000, 70001):
+        cases.append(rng.uniform(0, 3e-3, n))
+    # many exact ties: small multiples of 2^-60 added to a sum near 1 (ulp 2^-52)
+    cases.append(np.concatenate([[1.0], rng.integers(0, 1 << 12, 6000) * 2.0 ** -61]))
+    cases.append(np.concatenate([[0.75], np.full(4000, 2.0 ** -53), np.full(4000, 3 * 2.0 ** -54)]))
+    # binade crossings inside steps, values from 1e-12 to 10, and exact zeros
+    cases.append(10.0 ** rng.uniform(-12, 1, 30000))
+    z = rng.uniform(0, 1e-3, 20000)
+    z[rng.integers(0, 20000, 5000)] = 0.0
+    cases.append(z)
+    cases.append(np.full(100000, 0.1))
+    cases.append(np.concatenate([np.full(3000, 2.0 ** -30), [2.0 ** 20], np.full(3000, 2.0 ** -30)]))
+    for v in cases:
+        assert gpu_opt.ordered_sum(v) == _seq_sum(v)
+
+
+def test_exact_eval_large_clouds_bit_equal(gpu_opt, oracle):
+    s = make_scene(3, 120000, seed=41, ragged=True)
+    upload(gpu_opt, s)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    poses = random_poses(s, 5)
+    poses[0] = s.pose_true                      # tiny residuals
+    poses[1, :3] += 0.3                         # huge residuals
+    want = np.array([o.get_error(p, s.plane) for p in poses])
+    np.testing.assert_array_equal(gpu_opt.get_error(poses), want)
+
+
 def test_exact_eval_with_caller_planes(gpu_opt, oracle):
     s = make_scene(4, 500, seed=11, ragged=True)
     upload(gpu_opt, s)
