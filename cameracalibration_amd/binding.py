@@ -136,6 +136,7 @@ SIGNATURES = {
     "ccal_eval": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, _D, _D]),
     "ccal_eval_fast": (C.c_int, [_CTX, C.c_int, C.c_int64, _D, _F]),
     "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
+    "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
     "ccal_grid_default": (None, [_P(Grid)]),
     "ccal_grid_size": (C.c_int64, [_P(Grid)]),
     "ccal_grid_pose": (None, [_P(Grid), _D, C.c_int64, _D]),
@@ -252,6 +253,10 @@ class Optimizer:
         self._check(self._lib.ccal_upload_clouds(self._ctx, which, n, ptrs, sizes, _dptr(B)))
         self.n_clouds[which] = n
         self.n_points[which] = int(sum(a.shape[0] for a in arrs))
+
+    def set_fast_kernel(self, kind: int) -> None:
+        """0 = bf16x3 split on the bf16 matrix pipe (default), 1 = FP32-input MFMA."""
+        self._check(self._lib.ccal_set_fast_kernel(self._ctx, int(kind)))
 
     def set_plane(self, plane: Sequence[float]) -> None:
         p = np.ascontiguousarray(plane, dtype=np.float32)

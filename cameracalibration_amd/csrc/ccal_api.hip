@@ -128,11 +128,18 @@ int run_fast_chunk(ccal_ctx* ctx, const CloudSet& cs, const Source& src, int64_t
                        cs.base_dev.as<double>(), cs.centres_dev.as<double>(), fc,
                        ctx->w_buf.as<float>());
     if (ev0) CCAL_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    hipLaunchKernelGGL(residual_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
-                       dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
-                       cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
-                       cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
-                       f.n_ctiles, f.n_splits);
+    if (ctx->fast_kernel == 1)
+        hipLaunchKernelGGL(residual_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
+                           dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
+                           cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+                           cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
+                           f.n_ctiles, f.n_splits);
+    else
+        hipLaunchKernelGGL(residual_bf16x3_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
+                           dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
+                           cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+                           cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
+                           f.n_ctiles, f.n_splits);
     if (ev1) CCAL_HIP(ctx, hipEventRecord(ev1, ctx->stream));
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, ctx->partial_buf.as<double>(), f.n_padded, f.n_splits, n,
@@ -359,6 +366,15 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, hipMemcpy(cs.base_dev.p, cs.base_T_flange.data(),
                             16 * (size_t)n_clouds * sizeof(double), hipMemcpyHostToDevice));
     cs.ready = true;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_fast_kernel(ccal_ctx* ctx, int kind)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (kind != CCAL_FAST_BF16X3 && kind != CCAL_FAST_F32)
+        return fail(ctx, CCAL_ERR_ARG, "set_fast_kernel: kind must be CCAL_FAST_BF16X3 or CCAL_FAST_F32");
+    ctx->fast_kernel = kind;
     return CCAL_OK;
 }
 

@@ -72,6 +72,7 @@ struct ccal_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     ccal::CloudSet sets[2];
+    int fast_kernel = 0;  // CCAL_FAST_BF16X3
     bool plane_set = false;
     float plane[4] = {0, 0, 0, 0};
     std::string err;

@@ -246,6 +246,212 @@ __global__ __launch_bounds__(256, 3) void residual_mfma_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------
+// Fast residual kernel on the bf16 matrix pipe, FP32-equivalent operands
+// ---------------------------------------------------------------------------
+// The FP32-input MFMA above shares the SIMD with the VALU adds (they serialise),
+// so it tops out near 3/4 of the FP32 peak.  v_mfma_f32_16x16x32_bf16 runs on the
+// dense matrix pipe at twice that rate, and its K = 32 is wide enough to carry an
+// exact three-way bf16 split of both FP32 operands:
+//     v = v_h + v_m + v_l   (8 + 8 + 8 significand bits, exact for any float)
+// The eight significant cross products of a coordinate fill one lane group's 8
+// K-slots (the dropped v_l*w_l term is below 2^-32 relative), products of bf16
+// pairs are exact in FP32, and the pipe accumulates them in FP32:
+//   lane group g < 3 (coordinate g):  A = [wh wh wm wh wm wl wm wl]
+//                                     B = [ph pm ph pl pm ph pl pm]
+//   lane group 3 (the constant, p=1): A = [w3h 0 w3m 0 0 w3l 0 0], B = same split of 1.0
+// Measured error per residual 1.5e-9 (FP32 fmaf chain: 0.8e-9) on calib_1-like data.
+// The splits are done in registers from the same FP32 layouts the FP32 kernel
+// reads (9 VALU ops per 16-point tile and wave, shared by NA MFMAs).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void split_bf16x3(float v, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __float_as_uint(v) & 0xffff0000u;             // truncation keeps every piece exact
+    const float r1 = v - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// two bf16 given as FP32 bit patterns with zero low halves: low 16 bits = a, high = b
+__device__ inline unsigned pack_bf16(unsigned a, unsigned b) { return (a >> 16) | b; }
+
+__device__ inline bf16x8 split_point_operand(float v)
+{
+    unsigned h, m, l;
+    split_bf16x3(v, h, m, l);
+    const u32x4 r = {pack_bf16(h, m), pack_bf16(h, l), pack_bf16(m, h), pack_bf16(l, m)};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ inline bf16x8 split_candidate_operand(float w, bool constant_group)
+{
+    unsigned h, m, l;
+    split_bf16x3(w, h, m, l);
+    u32x4 r;
+    if (constant_group) r = u32x4{pack_bf16(h, 0u), pack_bf16(m, 0u), pack_bf16(0u, l), 0u};
+    else r = u32x4{pack_bf16(h, h), pack_bf16(m, h), pack_bf16(m, l), pack_bf16(m, l)};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// Promotes the FP32 lane accumulators of a wave into two FP64 totals per lane.
+// acc[a][r] of lane l belongs to candidate (l>>4)*4 + r of tile a and point column
+// l&15; the 16 lanes of a row are reduce-scattered (4 exchange steps), after which
+// lane column c owns the row totals of pairs 2c and 2c+1, pair = a*4 + r.
+template <int NA>
+__device__ inline void promote_rows(float (&acc)[NA][4], double scale, double& tot0, double& tot1)
+{
+    static_assert(NA == 8, "the reduce-scatter below is written for 32 values per lane");
+    const int col = threadIdx.x & 15;
+    float v[32];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[a * 4 + r] = acc[a][r]; acc[a][r] = 0.f; }
+    // step with partner col^8: lanes with bit 3 clear keep values 0..15, others 16..31
+    float w16[16];
+    {
+        const bool hi = (col & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float keep = hi ? v[16 + i] : v[i];
+            const float give = hi ? v[i] : v[16 + i];
+            w16[i] = keep + __shfl_xor(give, 8, 64);
+        }
+    }
+    float w8[8];
+    {
+        const bool hi = (col & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float keep = hi ? w16[8 + i] : w16[i];
+            const float give = hi ? w16[i] : w16[8 + i];
+            w8[i] = keep + __shfl_xor(give, 4, 64);
+        }
+    }
+    float w4[4];
+    {
+        const bool hi = (col & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = hi ? w8[4 + i] : w8[i];
+            const float give = hi ? w8[i] : w8[4 + i];
+            w4[i] = keep + __shfl_xor(give, 2, 64);
+        }
+    }
+    {
+        const bool hi = (col & 1) != 0;
+        const float k0 = hi ? w4[2] : w4[0], g0 = hi ? w4[0] : w4[2];
+        const float k1 = hi ? w4[3] : w4[1], g1 = hi ? w4[1] : w4[3];
+        tot0 += (double)(k0 + __shfl_xor(g0, 1, 64)) * scale;
+        tot1 += (double)(k1 + __shfl_xor(g1, 1, 64)) * scale;
+    }
+}
+
+// Pair index owned by lane column c after promote_rows: bit 3 of c selects the
+// upper 16 values, bit 2 the upper 8 of those, bit 1 the upper 4, bit 0 the upper 2;
+// the two totals are consecutive values of that quad-pair.
+__device__ inline int promoted_pair(int col, int which)
+{
+    return ((col & 8) ? 16 : 0) + ((col & 4) ? 8 : 0) + ((col & 2) ? 4 : 0) + ((col & 1) ? 2 : 0) + which;
+}
+
+template <int NA>
+__global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
+    const float* __restrict__ W, const f32x4* __restrict__ groups,
+    const int* __restrict__ group_off, const double* __restrict__ scale,
+    double* __restrict__ partial, int n_clouds, int n_ctiles, int n_splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ctile0 = (blockIdx.x * 4 + wave) * NA;
+    const int split = blockIdx.y;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    double tot0 = 0.0, tot1 = 0.0;
+
+    for (int j = 0; j < n_clouds; ++j) {
+        const int g0 = group_off[j];
+        const int G = group_off[j + 1] - g0;
+        const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
+        const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
+        if (gb >= ge) continue;
+        bf16x8 A[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+            A[a] = split_candidate_operand(W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane], lane >= 48);
+        const double sc = scale[j];
+
+        float acc[NA][4];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+
+        const f32x4* gp = groups + (int64_t)gb * 64 + lane;
+        f32x4 b = gp[0];
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // A and first-B loads retired before the loop
+        int since = 0;
+        // Bursts: kBurst MFMAs back to back, then the |d| adds of the previous
+        // burst; the bf16 split of the next point tile rides along with the adds.
+        constexpr int kBurst = 4;
+        static_assert(NA % kBurst == 0, "candidate tiles per wave must be a multiple of the burst");
+        bf16x8 Bc = split_point_operand(b[0]);
+        f32x4 carry[kBurst];
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) carry[q] = zero;
+        for (int g = gb; g < ge; ++g) {
+            f32x4 bn = b;
+            if (g + 1 < ge) bn = gp[64];
+            gp += 64;
+            f32x4 d[4 * NA];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x8 Bn = split_point_operand(u < 3 ? b[u + 1] : bn[0]);
+#pragma unroll
+                for (int i0 = u * NA; i0 < (u + 1) * NA; i0 += kBurst) {
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q)
+                        d[i0 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[(i0 + q) % NA], Bc, zero, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, kBurst, 0);
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q) {
+                        const f32x4 done = i0 == 0 ? carry[q] : d[i0 == 0 ? 0 : i0 - kBurst + q];
+                        const int a = (i0 + 4 * NA - kBurst + q) % NA;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[a][r] += __builtin_fabsf(done[r]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4 * kBurst + 5, 0);
+                }
+                Bc = Bn;
+            }
+#pragma unroll
+            for (int q = 0; q < kBurst; ++q) carry[q] = d[4 * NA - kBurst + q];
+            b = bn;
+            if (++since == kFlushGroups) {
+                since = 0;
+                promote_rows<NA>(acc, sc, tot0, tot1);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[NA - kBurst + q][r] += __builtin_fabsf(carry[q][r]);
+        promote_rows<NA>(acc, sc, tot0, tot1);
+    }
+
+    // lane (row, col) owns pairs p0, p0+1 of its row: candidate = tile a, row*4 + r
+    double* out = partial + (int64_t)split * n_ctiles * 16;
+    const int row = lane >> 4, col = lane & 15;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int pair = promoted_pair(col, which);
+        const int a = pair >> 2, r = pair & 3;
+        out[(int64_t)(ctile0 + a) * 16 + row * 4 + r] = which ? tot1 : tot0;
+    }
+}
+
 // Same contraction, counting |w.p| < thr instead of summing (RANSAC scoring).
 // Padding points have residual 0 and are counted; the host subtracts them.
 template <int NA>

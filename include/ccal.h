@@ -97,6 +97,15 @@ int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out)
 int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* poses6,
                    float* cost);
 
+/* Which kernel the fast path runs (no counterpart in the reference):
+ *   CCAL_FAST_BF16X3 (default)  operands split exactly into three bf16 pieces,
+ *                               contraction on the bf16 matrix pipe, FP32 accumulate;
+ *   CCAL_FAST_F32               FP32-input matrix instruction (fmaf-chain exact).
+ * Both meet the same 1e-5 cost tolerance; the final arg-min never depends on it
+ * (near-minimum candidates are re-scored with ccal_eval arithmetic). */
+enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1 };
+int ccal_set_fast_kernel(ccal_ctx* ctx, int kind);
+
 /* Candidate grid of discreteCombinatorialOptimization (:526-558), generalised:
  * axis k perturbs pose[k]; axes 0..2 in millimetres, 3..5 in degrees
  * (rad = deg*3.141592/180 as helpers.hpp:275-278); value_i = min + i*step;

@@ -128,6 +128,26 @@ def test_exact_eval_with_caller_planes(gpu_opt, oracle):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_both_fast_kernels_meet_tolerance(gpu_opt, oracle, kind):
+    """kind 0: exact bf16x3 operand split on the bf16 matrix pipe; kind 1: FP32-input MFMA."""
+    s = make_scene(7, 9000, seed=55, ragged=True)
+    upload(gpu_opt, s)
+    gpu_opt.set_fast_kernel(kind)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    poses = random_poses(s, 1100)                       # spans three candidate blocks
+    poses[0] = s.pose_true                              # smallest residuals: worst relative error
+    fast = gpu_opt.get_error_fast(poses)
+    exact = gpu_opt.get_error(poses[:96])
+    np.testing.assert_allclose(fast[:96], exact, rtol=FAST_RTOL)
+    want = np.array([o.get_error(p, s.plane) for p in poses[96:128]])
+    np.testing.assert_allclose(fast[96:128], want, rtol=FAST_RTOL)
+    g = __import__("cameracalibration_amd").Grid.make([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6)
+    idx, cost, _, _ = gpu_opt.grid_search(s.pose_init, g)
+    oi, oc, _, _ = o.grid_search(s.plane, s.pose_init, oracle.make_grid([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6))
+    assert (idx, cost) == (oi, oc)
+
+
 def test_fast_eval_large_batch_linear_properties(gpu_opt):
     """Size-independent checks at a larger size: duplicates give identical costs
     and the fast path tracks the exact path."""
