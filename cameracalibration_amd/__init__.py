@@ -27,5 +27,6 @@ from .binding import (  # noqa: F401
     read_point_cloud,
     run_config,
     voxel_grid,
+    write_config,
 )
 from .synthetic import SyntheticScene, make_scene  # noqa: F401

@@ -137,6 +137,8 @@ SIGNATURES = {
     "ccal_eval_fast": (C.c_int, [_CTX, C.c_int, C.c_int64, _D, _F]),
     "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
     "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
+    "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
+    "ccal_write_config": (C.c_int, [C.c_char_p, C.c_char_p, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
     "ccal_grid_size": (C.c_int64, [_P(Grid)]),
     "ccal_grid_pose": (None, [_P(Grid), _D, C.c_int64, _D]),
@@ -305,6 +307,20 @@ class Optimizer:
         self._check(self._lib.ccal_ordered_sum(self._ctx, _dptr(v), v.size, C.byref(out)))
         return float(out.value)
 
+    def point_errors(self, pose, plane=None, viewer_arithmetic: bool = False, which: int = CCAL_RAW):
+        """(distances [m], classes 0..3) of every point of the set for one pose."""
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        pl = None if plane is None else np.ascontiguousarray(plane, dtype=np.float64)
+        n = self.n_points[which]
+        dist = np.empty(n, dtype=np.float64)
+        cls = np.empty(n, dtype=np.uint8)
+        self._check(
+            self._lib.ccal_point_errors(self._ctx, which, _dptr(p), _dptr(pl) if pl is not None else None,
+                                        1 if viewer_arithmetic else 0, _dptr(dist),
+                                        cls.ctypes.data_as(_P(C.c_ubyte)))
+        )
+        return dist, cls
+
     def get_error_fast(self, poses, which: int = CCAL_DOWNSAMPLED) -> np.ndarray:
         P = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
         cost = np.empty(P.shape[0], dtype=np.float32)
@@ -410,3 +426,10 @@ def run_config(config: str, results: str, errors: str, verbose: bool = False) ->
                                         int(verbose), buf, len(buf))
     if rc != 0:
         raise CcalError(rc, buf.value.decode(errors="replace"))
+
+
+def write_config(config_in: str, config_out: str, pose) -> None:
+    p = np.ascontiguousarray(pose, dtype=np.float64)
+    rc = load_library().ccal_write_config(config_in.encode(), config_out.encode(), _dptr(p))
+    if rc != 0:
+        raise CcalError(rc, f"cannot write {config_out}")

@@ -486,6 +486,44 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
                             per_cloud_max);
 }
 
+extern "C" int ccal_point_errors(ccal_ctx* ctx, int which, const double pose[6], const double* plane4,
+                                 int arithmetic, double* dist_out, unsigned char* class_out)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!pose || (!dist_out && !class_out)) return fail(ctx, CCAL_ERR_ARG, "point_errors: null argument");
+    if (arithmetic != CCAL_POINT_OPTIMISER && arithmetic != CCAL_POINT_VIEWER)
+        return fail(ctx, CCAL_ERR_ARG, "point_errors: unknown arithmetic selector");
+    if (!plane4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "point_errors: plane not set");
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    std::vector<double> mats((size_t)cs.n_clouds * 12);
+    pose_matrices(cs, pose, mats.data());
+    double pl[kPlaneStride] = {0};
+    for (int e = 0; e < 4; ++e) pl[e] = plane4 ? plane4[e] : (double)ctx->plane[e];
+    pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+    CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
+    CCAL_HIP(ctx, ctx->planes_buf.ensure(sizeof pl));
+    CCAL_HIP(ctx, ctx->dist_buf.ensure(cs.total_pts * sizeof(double)));
+    CCAL_HIP(ctx, ctx->list_buf.ensure(cs.total_pts));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl, sizeof pl, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(point_error_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), arithmetic == CCAL_POINT_VIEWER ? 1 : 0,
+                       ctx->dist_buf.as<double>(), ctx->list_buf.as<unsigned char>());
+    CCAL_HIP(ctx, hipGetLastError());
+    if (dist_out)
+        CCAL_HIP(ctx, hipMemcpyAsync(dist_out, ctx->dist_buf.p, cs.total_pts * sizeof(double),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    if (class_out)
+        CCAL_HIP(ctx, hipMemcpyAsync(class_out, ctx->list_buf.p, cs.total_pts, hipMemcpyDeviceToHost,
+                                     ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
 // The accumulation primitive of the exact path on a caller-supplied array (see ccal.h).
 extern "C" int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out)
 {

@@ -32,6 +32,7 @@ struct Inputs {
     ccal_grid grid;
     int n_gpus = 1;
     ccal_gd_opts gd;
+    std::string config_out;   // optional <output><config>: refined config written here
 };
 
 std::string slurp(const std::string& path)
@@ -112,6 +113,7 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
     in.n_gpus = (int)num(*root, "data.device.gpus", 1);
     ccal_gd_default_opts(&in.gd);
     in.gd.max_iterations = (int)num(*root, "data.search.gd_max_iterations", in.gd.max_iterations);
+    in.config_out = trim(root->get("data.output.config", ""));
     return in;
 }
 
@@ -235,6 +237,8 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         for (int i = 0; i < 3; ++i) outfile << plane[i] << ", ";
         outfile << plane[3] << std::endl;
         print_error(ctx, r6.xval, C, errorfile);                                                            // :464
+        if (!in.config_out.empty() && ccal_write_config(config_path, in.config_out.c_str(), r6.xval) != CCAL_OK)
+            throw std::runtime_error("cannot write " + in.config_out);
 
         // ---- gradientDescentWithPlane (:466-524) --------------------------------------
         double x10[10];
@@ -262,6 +266,35 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
             std::strncpy(errbuf, e.what(), errbuf_len - 1);
             errbuf[errbuf_len - 1] = 0;
         }
+        return CCAL_ERR_IO;
+    }
+}
+
+// reference TODO.md:5: the input config with the refined transformation written back
+extern "C" int ccal_write_config(const char* config_in, const char* config_out, const double pose[6])
+{
+    if (!config_in || !config_out || !pose) return CCAL_ERR_ARG;
+    try {
+        std::string xml = slurp(config_in);
+        const std::string open_tag = "<approximate_transformation>", close_tag = "</approximate_transformation>";
+        const size_t b = xml.find(open_tag), e = xml.find(close_tag);
+        if (b == std::string::npos || e == std::string::npos || e < b)
+            throw std::runtime_error("config has no approximate_transformation element");
+        // keep the element's indentation
+        size_t line = xml.rfind('\n', b);
+        std::string indent = line == std::string::npos ? "" : xml.substr(line + 1, b - line - 1);
+        std::ostringstream body;
+        body.precision(17);
+        body << open_tag << "\n" << indent << "    <angle>rad</angle>\n" << indent << "    <metric>m</metric>\n"
+             << indent << "    <value>";
+        for (int i = 0; i < 6; ++i) body << pose[i] << (i < 5 ? "," : "");
+        body << "</value>\n" << indent;
+        xml.replace(b, e - b, body.str());
+        std::ofstream f(config_out, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot write the output config");
+        f << xml;
+        return CCAL_OK;
+    } catch (const std::exception&) {
         return CCAL_ERR_IO;
     }
 }

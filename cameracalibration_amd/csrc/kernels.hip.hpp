@@ -656,6 +656,48 @@ __device__ inline double exact_distance(const double* M, const double* pl, float
     return __builtin_fabs(num) / pl[4];
 }
 
+// The viewer's plane-mode colouring (src/algorithms.cpp:379-385) transforms the point with
+// the generic FP64 matrix product (k = 0..3 accumulated from zero) and does NOT round it to
+// float before the distance (pointToPlaneDistanceD, :255-258).
+__device__ inline double viewer_distance(const double* M, const double* pl, float x, float y, float z)
+{
+    const double xd = (double)x, yd = (double)y, zd = (double)z;
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double p = M[r * 4 + 0] * xd;
+        p = M[r * 4 + 1] * yd + p;
+        p = M[r * 4 + 2] * zd + p;
+        p = M[r * 4 + 3] * 1.0 + p;
+        q[r] = p;
+    }
+    const double num = pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3];
+    return __builtin_fabs(num) / pl[4];
+}
+
+// One pose: distance of every point (either arithmetic) and its error class
+// (src/algorithms.cpp:390-402: < 2.5 mm, < 5 mm, < 10 mm, else).
+__global__ __launch_bounds__(256) void point_error_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
+    const double* __restrict__ plane, int viewer_arithmetic, double* __restrict__ dist,
+    unsigned char* __restrict__ cls)
+{
+    __shared__ double sM[12];
+    __shared__ double sP[kPlaneStride];
+    const BlockDesc bd = blocks[blockIdx.x];
+    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+    if (threadIdx.x < kPlaneStride) sP[threadIdx.x] = plane[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+        const double d = viewer_arithmetic ? viewer_distance(sM, sP, xs[i], ys[i], zs[i])
+                                           : exact_distance(sM, sP, xs[i], ys[i], zs[i]);
+        dist[i] = d;
+        const double mm = d * 1000.0;
+        cls[i] = mm < 2.5 ? 0 : (mm < 5.0 ? 1 : (mm < 10.0 ? 2 : 3));
+    }
+}
+
 // Distances of every point for n_poses poses: dist[k][i] (pose-major, i = global
 // point index).  The sums are NOT formed here: the reference adds the distances
 // of a cloud one by one in point order

@@ -84,6 +84,19 @@ int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
               const double* planes4, double* cost,
               double* per_cloud_mean, double* per_cloud_max);
 
+/* Per-point distances and error classes for one pose (all points of the set, clouds back to
+ * back in upload order).  Replaces the per-point loops of the raw-cloud error report
+ * (printError, :379-405) and of the viewer's plane-mode colouring
+ * (src/algorithms.cpp:360-406; thresholds 2.5 / 5 / 10 mm -> class 0 / 1 / 2, else 3).
+ *   arithmetic  CCAL_POINT_OPTIMISER: the optimiser's (point rounded to float, :303-304)
+ *               CCAL_POINT_VIEWER:    the viewer's (FP64 point, generic matrix product,
+ *                                     src/algorithms.cpp:379-385, :255-258)
+ *   plane4      NULL = context plane; else 4 doubles
+ *   dist_out    NULL or total-points doubles [m];  class_out  NULL or total-points bytes */
+enum { CCAL_POINT_OPTIMISER = 0, CCAL_POINT_VIEWER = 1 };
+int ccal_point_errors(ccal_ctx* ctx, int which, const double pose[6], const double* plane4,
+                      int arithmetic, double* dist_out, unsigned char* class_out);
+
 /* The accumulation of :305 (`average += distance`, one rounding per add, in
  * order) for n non-negative doubles, computed on the GPU by the same kernel
  * ccal_eval uses: out = ((0 + v[0]) + v[1]) + ... bit for bit.  Exposed so the
@@ -211,6 +224,12 @@ int  ccal_read_point_cloud(const char* filename, const char* metric, float** xyz
  * n points; n_out receives the number of centroids. */
 int  ccal_voxel_grid(const float* xyz, size_t n, float leaf, float* xyz_out, size_t* n_out);
 void ccal_free(void* p);
+
+/* Writes a copy of `config_in` whose approximate_transformation holds `pose` (metres,
+ * radians): the "output new config file after running the optimization" item of the
+ * reference's TODO.md:5.  ccal_run_config calls it when the config has an
+ * <output><config>path</config></output> node. */
+int  ccal_write_config(const char* config_in, const char* config_out, const double pose[6]);
 
 /* The optimiser executable as one call: replaces main() + getInputs() + the
  * three drivers (camera_calibration_optimization.cpp:560-581, :148-278,

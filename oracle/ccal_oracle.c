@@ -719,3 +719,47 @@ void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float
     if (best_hyp_out) *best_hyp_out = best_h;
     free(q); free(off); free(M);
 }
+
+/* ------------------------------------------------------------------ */
+/* per-point distances and error classes                               */
+/* ------------------------------------------------------------------ */
+
+/* arithmetic 0: the optimiser's loop body (camera_calibration_optimization.cpp:389-404);
+ * arithmetic 1: the viewer's plane-mode colouring (src/algorithms.cpp:379-385 with
+ * apply_transformation = generic FP64 product, helpers.cpp:32-42, and
+ * pointToPlaneDistanceD, algorithms.cpp:255-258).  Classes: algorithms.cpp:390-402. */
+void orc_point_errors(const orc_scene* s, const double pose[6], const double plane[4],
+                      int arithmetic, double* dist_out, unsigned char* class_out)
+{
+    size_t w = 0;
+    for (int j = 0; j < s->n_clouds; ++j) {
+        double M[16];
+        cloud_matrix(s, j, pose, M);
+        const float* pts = s->xyz[j];
+        for (size_t i = 0; i < s->n_pts[j]; ++i, ++w) {
+            double distance;
+            if (arithmetic == 0) {
+                float out[3];
+                orc_transform_point(M, pts + 3 * i, out);
+                distance = orc_distance_planed(plane, out);
+            } else {
+                double q[3];
+                for (int r = 0; r < 3; ++r) {
+                    double p = 0.0;
+                    p = M[r * 4 + 0] * (double)pts[3 * i + 0] + p;
+                    p = M[r * 4 + 1] * (double)pts[3 * i + 1] + p;
+                    p = M[r * 4 + 2] * (double)pts[3 * i + 2] + p;
+                    p = M[r * 4 + 3] * 1.0 + p;
+                    q[r] = p;
+                }
+                distance = fabs(plane[0] * q[0] + plane[1] * q[1] + plane[2] * q[2] + plane[3]) /
+                           (sqrt(pow(plane[0], 2) + pow(plane[1], 2) + pow(plane[2], 2)));
+            }
+            if (dist_out) dist_out[w] = distance;
+            if (class_out) {
+                double mm = distance * 1000.0;
+                class_out[w] = mm < 2.5 ? 0 : (mm < 5.0 ? 1 : (mm < 10.0 ? 2 : 3));
+            }
+        }
+    }
+}

@@ -129,6 +129,11 @@ void orc_gd_minimize(const orc_scene* s, const float plane[4], int dim, const do
 void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
                       uint64_t seed, float plane_out[4], int64_t* inliers_out, int* best_hyp_out);
 
+/* Per-point distances / classes: optimiser arithmetic (0, :389-404) or the viewer's
+ * plane-mode colouring arithmetic (1, src/algorithms.cpp:379-402). */
+void orc_point_errors(const orc_scene* s, const double pose[6], const double plane[4],
+                      int arithmetic, double* dist_out, unsigned char* class_out);
+
 /* stof-based parsers: camera_calibration_optimization.cpp:70-98, helpers.cpp:238-259 */
 int orc_parse_pose_csv(const char* line, double scale, int angle_is_degree, double pose[6]);
 int orc_file_id(const char* filename); /* :131-146 */

@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         ]
         L.orc_ransac_plane.argtypes = [C.POINTER(Scene), _D, C.c_int, C.c_float, C.c_uint64, _F,
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_point_errors.argtypes = [C.POINTER(Scene), _D, _D, C.c_int, _D, C.POINTER(C.c_ubyte)]
         L.orc_parse_pose_csv.restype = C.c_int
         L.orc_parse_pose_csv.argtypes = [C.c_char_p, C.c_double, C.c_int, _D]
         L.orc_file_id.restype = C.c_int
@@ -186,6 +187,16 @@ class OracleScene:
         out = np.empty((total, 3), dtype=np.float32)
         n = lib().orc_combined_cloud(C.byref(self.c), _d(p), _f(out))
         return out[:n]
+
+    def point_errors(self, pose, plane, arithmetic: int):
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        pl = np.ascontiguousarray(plane, dtype=np.float64)
+        n = sum(c.shape[0] for c in self.clouds)
+        dist = np.empty(n)
+        cls = np.empty(n, dtype=np.uint8)
+        lib().orc_point_errors(C.byref(self.c), _d(p), _d(pl), int(arithmetic), _d(dist),
+                               cls.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return dist, cls
 
     def ransac_plane(self, pose, n_hyp: int, threshold: float, seed: int):
         p = np.ascontiguousarray(pose, dtype=np.float64)

@@ -77,6 +77,7 @@ def build_case(tmp, ccal):
         <rotation_deg><min>-4</min><step>2</step><count>5</count></rotation_deg>
         <gd_max_iterations>12</gd_max_iterations>
     </search>
+    <output><config>{tmp}/refined.xml</config></output>
 </data>
 """)
     return cfg, files, order, ik, init
@@ -132,6 +133,13 @@ def test_cli_end_to_end(tmp_path, ccal, oracle, gpu_opt):
         assert got_res == res * run + [""]
         assert got_err == err * run + [""]
     assert "True: " in p.stdout and "Starting optimization" in p.stdout
+    # the refined config (reference TODO.md:5) carries the 6-D GD result to 17 digits
+    refined = open(tmp_path / "refined.xml").read()
+    val = refined[refined.index("<value>") + 7:refined.index("</value>")]
+    got = np.array([float(v) for v in val.split(",")])
+    want = [float(v) for v in res[6].split(", ")]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    assert "<gd_max_iterations>12</gd_max_iterations>" in refined
 
 
 def test_cli_usage_and_errors(tmp_path):

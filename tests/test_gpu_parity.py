@@ -75,6 +75,28 @@ def test_exact_and_fast_vs_oracle(gpu_opt, oracle, n_clouds, n_points, ragged):
     np.testing.assert_array_equal(mx, omx)
 
 
+@pytest.mark.parametrize("viewer", [False, True])
+def test_point_errors_and_classes(gpu_opt, oracle, calib1, viewer):
+    sub = [calib1["sub_%d" % i] for i in range(4)]
+    gpu_opt.upload_clouds(1, sub, calib1["base_T_flange"])
+    gpu_opt.set_plane(calib1["plane_full"])
+    o = oracle.OracleScene(sub, calib1["base_T_flange"])
+    pose = calib1["pose_init"].copy()
+    pose[2] += 0.004                                  # spreads the points over all four classes
+    want_d, want_c = o.point_errors(pose, calib1["plane_full"].astype(np.float64), int(viewer))
+    got_d, got_c = gpu_opt.point_errors(pose, viewer_arithmetic=viewer, which=1)
+    np.testing.assert_array_equal(got_d, want_d)
+    np.testing.assert_array_equal(got_c, want_c)
+    assert set(np.unique(got_c)) >= {0, 1, 2}
+    if not viewer:
+        # consistent with the per-cloud report of the same pose
+        _, mean, mx = gpu_opt.per_cloud_error(pose, which=1)
+        off = np.cumsum([0] + [len(c) for c in sub])
+        for j in range(4):
+            assert mx[j] == got_d[off[j]:off[j + 1]].max()
+            assert mean[j] == pytest.approx(got_d[off[j]:off[j + 1]].mean(), rel=1e-12)
+
+
 def _seq_sum(v):
     s = np.float64(0.0)
     for x in v:

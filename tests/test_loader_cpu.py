@@ -139,3 +139,31 @@ def test_run_config_reports_bad_inputs(ccal, tmp_path):
         ccal.run_config(str(cfg), res, err)
     # the reference writes the "Results:" header before reading anything (:571-574)
     assert open(res).read().startswith("Results: ")
+
+
+def test_write_config_round_trip(ccal, tmp_path):
+    src = tmp_path / "in.xml"
+    src.write_text("""<?xml version="1.0"?>
+<data>
+    <camera>
+        <transformations>
+            <approximate_transformation>
+                <angle>degree</angle>
+                <metric>mm</metric>
+                <value>1,2,3,4,5,6</value>
+            </approximate_transformation>
+        </transformations>
+        <metric>m</metric>
+    </camera>
+</data>
+""")
+    pose = np.array([0.0204504123456789, 0.111258, -0.0505291, -3.15376, 1e-9, 1.58043])
+    dst = tmp_path / "out.xml"
+    ccal.write_config(str(src), str(dst), pose)
+    text = dst.read_text()
+    assert "<angle>rad</angle>" in text and "<metric>m</metric>" in text and "degree" not in text
+    val = text[text.index("<value>") + 7:text.index("</value>")]
+    np.testing.assert_array_equal(np.array([float(v) for v in val.split(",")]), pose)   # 17 digits round-trip
+    assert text.count("<camera>") == 1 and text.strip().endswith("</data>")
+    with pytest.raises(ccal.CcalError):
+        ccal.write_config(str(tmp_path / "missing.xml"), str(dst), pose)
