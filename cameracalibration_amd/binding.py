@@ -131,6 +131,9 @@ SIGNATURES = {
     "ccal_status_string": (C.c_char_p, [C.c_int]),
     "ccal_device_count": (C.c_int, []),
     "ccal_upload_clouds": (C.c_int, [_CTX, C.c_int, C.c_int, _P(_F), _P(C.c_size_t), _D]),
+    "ccal_downsample_raw": (C.c_int, [_CTX, C.c_float, _P(C.c_size_t)]),
+    "ccal_cloud_size": (C.c_int, [_CTX, C.c_int, C.c_int, _P(C.c_size_t)]),
+    "ccal_download_cloud": (C.c_int, [_CTX, C.c_int, C.c_int, _F]),
     "ccal_set_plane": (C.c_int, [_CTX, _F]),
     "ccal_get_plane": (C.c_int, [_CTX, _F]),
     "ccal_eval": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, _D, _D]),
@@ -255,6 +258,22 @@ class Optimizer:
         self._check(self._lib.ccal_upload_clouds(self._ctx, which, n, ptrs, sizes, _dptr(B)))
         self.n_clouds[which] = n
         self.n_points[which] = int(sum(a.shape[0] for a in arrs))
+
+    def downsample_raw(self, leaf: float = 0.02):
+        """Device voxel grid: RAW set -> DOWNSAMPLED set; returns the per-cloud centroid counts."""
+        n = self.n_clouds[CCAL_RAW]
+        sizes = (C.c_size_t * max(n, 1))()
+        self._check(self._lib.ccal_downsample_raw(self._ctx, float(leaf), sizes))
+        self.n_clouds[CCAL_DOWNSAMPLED] = n
+        self.n_points[CCAL_DOWNSAMPLED] = int(sum(sizes[:n]))
+        return [int(v) for v in sizes[:n]]
+
+    def download_cloud(self, which: int, cloud: int) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._check(self._lib.ccal_cloud_size(self._ctx, which, cloud, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.float32)
+        self._check(self._lib.ccal_download_cloud(self._ctx, which, cloud, out.ctypes.data_as(_F)))
+        return out
 
     def set_fast_kernel(self, kind: int) -> None:
         """0 = bf16x3 split on the bf16 matrix pipe (default), 1 = FP32-input MFMA."""

@@ -851,3 +851,4 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
 }
 
 #include "ransac_impl.hpp"
+#include "voxel_impl.hpp"

@@ -71,10 +71,7 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
         Cloud all = read_point_cloud(filename, camera_metric);                     // :165
         Cloud kept = filter_z(all, 0.8f);                                          // :167-169
         if (kept.empty()) throw std::runtime_error(filename + ": no points with z <= 0.8");
-        Cloud ds = voxel_grid(kept, 0.02f);                                        // :199-203
-        if (chatty) std::cout << "Filtered Clouds Size: " << ds.size() / 3 << std::endl;
-        in.raw.push_back(std::move(kept));
-        in.down.push_back(std::move(ds));
+        in.raw.push_back(std::move(kept));   // the voxel grid of :199-203 runs on the device after the upload
     }
 
     const XmlNode* ik = root->find("data.camera.transformations.inverse_kinematics.location");
@@ -167,7 +164,7 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         errorfile << "Results: " << config_path << std::endl;                                               // :572
 
         Inputs in = load_inputs(config_path, chatty);
-        const int C = (int)in.down.size();
+        const int C = (int)in.raw.size();
         const int avail = ccal_device_count();
         if (avail < 1) throw std::runtime_error("no GPU visible: the optimiser has no CPU path");
         const int n_gpus = std::max(1, std::min(in.n_gpus, avail));
@@ -175,10 +172,22 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
             ccal_ctx* c = nullptr;
             Check{nullptr}(ccal_create(d, &c), "ccal_create");
             ctxs.push_back(c);
-            upload(c, CCAL_DOWNSAMPLED, in.down, in.base_T_flange);
         }
         ccal_ctx* ctx = ctxs[0];
+        // raw clouds go to the device once; VoxelGrid(0.02) (:196-205) runs there
         upload(ctx, CCAL_RAW, in.raw, in.base_T_flange);
+        std::vector<size_t> n_down(C);
+        Check{ctx}(ccal_downsample_raw(ctx, 0.02f, n_down.data()), "downsample_raw");
+        if (chatty)
+            for (int j = 0; j < C; ++j) std::cout << "Filtered Clouds Size: " << n_down[j] << std::endl;   // :204
+        if (n_gpus > 1) {
+            in.down.resize(C);
+            for (int j = 0; j < C; ++j) {
+                in.down[j].resize(3 * n_down[j]);
+                Check{ctx}(ccal_download_cloud(ctx, CCAL_DOWNSAMPLED, j, in.down[j].data()), "download_cloud");
+            }
+            for (int d = 1; d < n_gpus; ++d) upload(ctxs[d], CCAL_DOWNSAMPLED, in.down, in.base_T_flange);
+        }
 
         // plane from every raw point carried to the base frame by the initial pose (:240-277)
         float plane[4];

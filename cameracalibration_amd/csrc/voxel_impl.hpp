@@ -1,0 +1,250 @@
+// voxel_impl.hpp -- device voxel-grid downsample (included at the end of ccal_api.hip).
+//
+// Stands in for pcl::VoxelGrid<PointXYZ> at src/camera_calibration_optimization.cpp:196-205
+// (leaf 0.02f) with the same definition as the host filter (csrc/host/cloud_io.cpp): PCL's
+// index arithmetic in float, voxels emitted in ascending linear index, the points of a voxel
+// accumulated in input order in float.  Per cloud: bounds reduction -> keys -> stable radix
+// sort of (key, point index) -> run-length encode -> one thread per voxel sums its run.
+#pragma once
+
+#include <rocprim/rocprim.hpp>
+
+namespace ccal {
+
+__global__ __launch_bounds__(256) void voxel_bounds_kernel(const float* __restrict__ xs,
+                                                           const float* __restrict__ ys,
+                                                           const float* __restrict__ zs, int64_t begin,
+                                                           int64_t end, float* __restrict__ out /* 6*blocks */)
+{
+    __shared__ float red[4][6];
+    float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    for (int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float v[3] = {xs[i], ys[i], zs[i]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!__builtin_isfinite(v[k])) continue;
+            mn[k] = v[k] < mn[k] ? v[k] : mn[k];
+            mx[k] = v[k] > mx[k] ? v[k] : mx[k];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float a = __shfl_xor(mn[k], off, 64), b = __shfl_xor(mx[k], off, 64);
+            mn[k] = a < mn[k] ? a : mn[k];
+            mx[k] = b > mx[k] ? b : mx[k];
+        }
+        if (lane == 0) { red[wave][k] = mn[k]; red[wave][3 + k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? (red[w][k] < v ? red[w][k] : v) : (red[w][k] > v ? red[w][k] : v);
+        out[blockIdx.x * 6 + k] = v;
+    }
+}
+
+struct VoxelDims {
+    float inv;
+    float minb[3];
+    long long div0, div01;
+};
+
+__global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xs,
+                                                         const float* __restrict__ ys,
+                                                         const float* __restrict__ zs, int64_t begin,
+                                                         int64_t n, VoxelDims d,
+                                                         unsigned long long* __restrict__ keys,
+                                                         unsigned int* __restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xs[begin + i], y = ys[begin + i], z = zs[begin + i];
+    unsigned long long key = ~0ull;   // non-finite points sort last and are dropped
+    if (__builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z)) {
+        const long long i0 = (long long)(floorf(x * d.inv) - d.minb[0]);
+        const long long i1 = (long long)(floorf(y * d.inv) - d.minb[1]);
+        const long long i2 = (long long)(floorf(z * d.inv) - d.minb[2]);
+        key = (unsigned long long)(i0 + i1 * d.div0 + i2 * d.div01);
+    }
+    keys[i] = key;
+    idx[i] = (unsigned int)i;
+}
+
+// One thread per voxel: float sums of its points in input order (the sort is stable).
+__global__ __launch_bounds__(256) void voxel_centroid_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    int64_t begin, const unsigned long long* __restrict__ unique_keys,
+    const unsigned int* __restrict__ counts, const unsigned int* __restrict__ offsets,
+    const unsigned int* __restrict__ sorted_idx, unsigned int n_runs, float* __restrict__ out /* AoS xyz */)
+{
+    const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_runs || unique_keys[v] == ~0ull) return;
+    const unsigned int o = offsets[v], c = counts[v];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (unsigned int t = 0; t < c; ++t) {
+        const int64_t i = begin + sorted_idx[o + t];
+        sx += xs[i]; sy += ys[i]; sz += zs[i];
+    }
+    const float cnt = (float)c;
+    out[3 * (size_t)v + 0] = sx / cnt;
+    out[3 * (size_t)v + 1] = sy / cnt;
+    out[3 * (size_t)v + 2] = sz / cnt;
+}
+
+} // namespace ccal
+
+namespace {
+
+// Voxel centroids of points [begin, begin+n) of a resident set, appended to `out`.
+int voxel_downsample_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int64_t n, float leaf,
+                           std::vector<float>& out)
+{
+    hipStream_t st = ctx->stream;
+    const float* xs = cs.xs.as<float>();
+    const float* ys = cs.ys.as<float>();
+    const float* zs = cs.zs.as<float>();
+    const int nb = (int)std::min<int64_t>(256, (n + 255) / 256);
+    CCAL_HIP(ctx, ctx->psum_buf.ensure((size_t)nb * 6 * sizeof(float)));
+    hipLaunchKernelGGL(voxel_bounds_kernel, dim3(nb), dim3(256), 0, st, xs, ys, zs, begin, begin + n,
+                       ctx->psum_buf.as<float>());
+    std::vector<float> hb((size_t)nb * 6);
+    CCAL_HIP(ctx, hipMemcpyAsync(hb.data(), ctx->psum_buf.p, hb.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    CCAL_HIP(ctx, hipStreamSynchronize(st));
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int b = 0; b < nb; ++b)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::min(mn[k], hb[(size_t)b * 6 + k]);
+            mx[k] = std::max(mx[k], hb[(size_t)b * 6 + 3 + k]);
+        }
+    if (!(mn[0] <= mx[0])) return CCAL_OK;   // no finite point
+    VoxelDims d;
+    d.inv = 1.0f / leaf;
+    long long minb[3], div[3];
+    for (int k = 0; k < 3; ++k) {
+        minb[k] = (long long)std::floor(mn[k] * d.inv);
+        div[k] = (long long)std::floor(mx[k] * d.inv) - minb[k] + 1;
+        d.minb[k] = (float)minb[k];
+    }
+    d.div0 = div[0];
+    d.div01 = div[0] * div[1];
+    const double cells = (double)div[0] * (double)div[1] * (double)div[2];
+    if (!(cells < 9.0e18)) return fail(ctx, CCAL_ERR_ARG, "voxel grid: leaf too small for the cloud extent");
+    int key_bits = 1;
+    while (key_bits < 64 && std::ldexp(1.0, key_bits) <= cells) ++key_bits;
+
+    // keys, sort, run-length encode
+    const size_t N = (size_t)n;
+    DevBuf keys, keys2, idx, idx2, uniq, counts, offsets, nruns, tmp;
+    auto rel = [&]() { for (DevBuf* b : {&keys, &keys2, &idx, &idx2, &uniq, &counts, &offsets, &nruns, &tmp}) b->release(); };
+#define VOX_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rel(); return fail(ctx, CCAL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
+    VOX_HIP(keys.ensure(N * 8)); VOX_HIP(keys2.ensure(N * 8)); VOX_HIP(idx.ensure(N * 4)); VOX_HIP(idx2.ensure(N * 4));
+    VOX_HIP(uniq.ensure(N * 8)); VOX_HIP(counts.ensure(N * 4)); VOX_HIP(offsets.ensure(N * 4)); VOX_HIP(nruns.ensure(4));
+    hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xs, ys, zs, begin, n, d,
+                       keys.as<unsigned long long>(), idx.as<unsigned int>());
+    // non-finite keys are all ones: sort every bit when any may be present
+    const unsigned end_bit = 64;
+    (void)key_bits;
+    size_t tmp_bytes = 0;
+    VOX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
+                                      idx.as<unsigned int>(), idx2.as<unsigned int>(), N, 0, end_bit, st));
+    VOX_HIP(tmp.ensure(tmp_bytes));
+    VOX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
+                                      idx.as<unsigned int>(), idx2.as<unsigned int>(), N, 0, end_bit, st));
+    size_t tmp2 = 0;
+    VOX_HIP(rocprim::run_length_encode(nullptr, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
+                                       uniq.as<unsigned long long>(), counts.as<unsigned int>(),
+                                       nruns.as<unsigned int>(), st));
+    VOX_HIP(tmp.ensure(tmp2));
+    VOX_HIP(rocprim::run_length_encode(tmp.p, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
+                                       uniq.as<unsigned long long>(), counts.as<unsigned int>(),
+                                       nruns.as<unsigned int>(), st));
+    unsigned int n_runs = 0;
+    VOX_HIP(hipMemcpyAsync(&n_runs, nruns.p, 4, hipMemcpyDeviceToHost, st));
+    VOX_HIP(hipStreamSynchronize(st));
+    size_t tmp3 = 0;
+    VOX_HIP(rocprim::exclusive_scan(nullptr, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u, n_runs,
+                                    rocprim::plus<unsigned int>(), st));
+    VOX_HIP(tmp.ensure(tmp3));
+    VOX_HIP(rocprim::exclusive_scan(tmp.p, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u, n_runs,
+                                    rocprim::plus<unsigned int>(), st));
+    // the all-ones run (non-finite points), if any, is the last one
+    unsigned long long last_key = 0;
+    VOX_HIP(hipMemcpyAsync(&last_key, uniq.as<unsigned long long>() + (n_runs - 1), 8, hipMemcpyDeviceToHost, st));
+    VOX_HIP(hipStreamSynchronize(st));
+    const unsigned int n_vox = last_key == ~0ull ? n_runs - 1 : n_runs;
+    DevBuf cent;
+    VOX_HIP(cent.ensure((size_t)std::max(1u, n_vox) * 3 * sizeof(float)));
+    if (n_vox) {
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_vox + 255) / 256), dim3(256), 0, st, xs, ys, zs, begin,
+                           uniq.as<unsigned long long>(), counts.as<unsigned int>(), offsets.as<unsigned int>(),
+                           idx2.as<unsigned int>(), n_vox, cent.as<float>());
+        const size_t o = out.size();
+        out.resize(o + (size_t)n_vox * 3);
+        hipError_t e = hipMemcpyAsync(out.data() + o, cent.p, (size_t)n_vox * 3 * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { cent.release(); rel(); return fail(ctx, CCAL_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    cent.release();
+    rel();
+#undef VOX_HIP
+    return CCAL_OK;
+}
+
+} // namespace
+
+extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
+{
+    if (int rc = check_set(ctx, CCAL_RAW)) return rc;
+    if (!(leaf > 0.f)) return fail(ctx, CCAL_ERR_ARG, "downsample_raw: leaf must be positive");
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& raw = ctx->sets[CCAL_RAW];
+    const int C = raw.n_clouds;
+    std::vector<std::vector<float>> down(C);
+    int64_t begin = 0;
+    for (int j = 0; j < C; ++j) {
+        if (int rc = voxel_downsample_range(ctx, raw, begin, (int64_t)raw.n_pts[j], leaf, down[j])) return rc;
+        begin += (int64_t)raw.n_pts[j];
+        if (down[j].empty()) return fail(ctx, CCAL_ERR_ARG, "downsample_raw: a cloud has no finite point");
+    }
+    std::vector<const float*> ptrs(C);
+    std::vector<size_t> sizes(C);
+    for (int j = 0; j < C; ++j) {
+        ptrs[j] = down[j].data();
+        sizes[j] = down[j].size() / 3;
+        if (n_pts_out) n_pts_out[j] = sizes[j];
+    }
+    const std::vector<double> B = raw.base_T_flange;   // upload replaces sets[which] only, copy is defensive
+    return ccal_upload_clouds(ctx, CCAL_DOWNSAMPLED, C, ptrs.data(), sizes.data(), B.data());
+}
+
+extern "C" int ccal_cloud_size(const ccal_ctx* ctx, int which, int cloud, size_t* n_out)
+{
+    if (!ctx || !n_out || (which != CCAL_DOWNSAMPLED && which != CCAL_RAW)) return CCAL_ERR_ARG;
+    const CloudSet& cs = ctx->sets[which];
+    if (!cs.ready) return CCAL_ERR_STATE;
+    if (cloud < 0 || cloud >= cs.n_clouds) return CCAL_ERR_ARG;
+    *n_out = cs.n_pts[cloud];
+    return CCAL_OK;
+}
+
+extern "C" int ccal_download_cloud(ccal_ctx* ctx, int which, int cloud, float* xyz_out)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    if (cloud < 0 || cloud >= cs.n_clouds || !xyz_out) return fail(ctx, CCAL_ERR_ARG, "download_cloud: bad argument");
+    if (int rc = bind(ctx)) return rc;
+    size_t off = 0;
+    for (int j = 0; j < cloud; ++j) off += cs.n_pts[j];
+    const size_t n = cs.n_pts[cloud];
+    std::vector<float> x(n), y(n), z(n);
+    CCAL_HIP(ctx, hipMemcpy(x.data(), cs.xs.as<float>() + off, n * sizeof(float), hipMemcpyDeviceToHost));
+    CCAL_HIP(ctx, hipMemcpy(y.data(), cs.ys.as<float>() + off, n * sizeof(float), hipMemcpyDeviceToHost));
+    CCAL_HIP(ctx, hipMemcpy(z.data(), cs.zs.as<float>() + off, n * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) { xyz_out[3 * i] = x[i]; xyz_out[3 * i + 1] = y[i]; xyz_out[3 * i + 2] = z[i]; }
+    return CCAL_OK;
+}

@@ -65,6 +65,16 @@ int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                        const float* const* xyz, const size_t* n_pts,
                        const double* base_T_flange);
 
+/* Builds the DOWNSAMPLED set on the device from the resident RAW set: per cloud the
+ * voxel-grid centroid filter that stands in for pcl::VoxelGrid at
+ * camera_calibration_optimization.cpp:196-205 (same definition as ccal_voxel_grid, bit-equal
+ * output).  n_pts_out: NULL or n_clouds entries.  The raw clouds are uploaded once; nothing but
+ * the few hundred centroids per cloud crosses PCIe again. */
+int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out);
+/* Size / coordinates (AoS xyz, n*3 floats) of one resident cloud. */
+int ccal_cloud_size(const ccal_ctx* ctx, int which, int cloud, size_t* n_out);
+int ccal_download_cloud(ccal_ctx* ctx, int which, int cloud, float* xyz_out);
+
 /* The reference plane `Optimizer::plane` (Eigen::Vector4f, :53, set at :274). */
 int ccal_set_plane(ccal_ctx* ctx, const float plane[4]);
 int ccal_get_plane(const ccal_ctx* ctx, float plane[4]);

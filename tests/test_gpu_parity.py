@@ -97,6 +97,28 @@ def test_point_errors_and_classes(gpu_opt, oracle, calib1, viewer):
             assert mean[j] == pytest.approx(got_d[off[j]:off[j + 1]].mean(), rel=1e-12)
 
 
+def test_device_voxel_grid_matches_oracle(gpu_opt, oracle, calib1):
+    rng = np.random.default_rng(23)
+    clouds = [calib1["sub_0"], calib1["sub_3"], rng.uniform(-0.3, 0.4, (70000, 3)).astype(np.float32)]
+    dirty = rng.uniform(0, 0.2, (5000, 3)).astype(np.float32)
+    dirty[::97, 1] = np.nan
+    dirty[5::131, 0] = np.inf
+    clouds.append(dirty)
+    B = np.tile(np.eye(4), (4, 1, 1))
+    gpu_opt.upload_clouds(1, clouds, B)
+    for leaf in (0.02, 0.005):
+        sizes = gpu_opt.downsample_raw(leaf)
+        for j, c in enumerate(clouds):
+            want = oracle.voxel_grid(c, leaf)
+            got = gpu_opt.download_cloud(0, j)
+            assert sizes[j] == len(want)
+            np.testing.assert_array_equal(got, want)
+    # raw set is still intact and the objective runs on the new downsampled set
+    np.testing.assert_array_equal(gpu_opt.download_cloud(1, 0), clouds[0])
+    gpu_opt.set_plane([0, 0, 1, -0.1])
+    assert np.isfinite(gpu_opt.get_error(np.zeros(6)))
+
+
 def _seq_sum(v):
     s = np.float64(0.0)
     for x in v:
