@@ -15,9 +15,13 @@
 //                f(x-alpha g) <= f - c1 alpha g.g  and  g.g(x-alpha g) <= c2 g.g
 //       step   = momentum*step + (1-momentum)*alpha*g
 //
-// Every stencil (the point itself and +-eps/2 along each axis) is one batched
-// call into the exact objective; several independent descents advance in lock
-// step and share those calls.
+// Every stencil (the point itself and +-eps/2 along each axis) is evaluated by
+// batched calls into the exact objective; several independent descents advance
+// in lock step and share those calls.  The backtracking trials of one line
+// search are known in advance (alpha = 0.8^k), so a run of them is evaluated
+// speculatively in one pass and then consumed in order with exactly the
+// sequential accept/continue logic; values past the accepted trial are dropped
+// (and not counted), so iterates and evaluation counts equal the one-by-one run.
 #include "ccal_internal.hpp"
 
 #include <cfloat>
@@ -38,8 +42,32 @@ struct Machine {
     double alpha = 0.0, gg = 0.0, xn[10];
     int ls_it = 0;
     enum Phase { MAIN, TRIAL, DONE } phase = DONE;
+    // speculation: trials per request (first request of a line search / later ones)
+    int last_trials = 3;
+    bool first_request = true;
+    static constexpr int kMaxSpeculated = 48;
 
     int stencil() const { return 1 + 2 * D; }
+
+    // trials the next request evaluates (>= 1 in TRIAL phase)
+    int planned_trials() const
+    {
+        if (phase != TRIAL) return 1;
+        int want = first_request ? last_trials + 1 : 4;
+        if (want > kMaxSpeculated) want = kMaxSpeculated;
+        if (want < 1) want = 1;
+        int n = 1;
+        double a = alpha;
+        int lit = ls_it + 1;                     // the first trial of the request is always allowed
+        while (n < want && (o.wolfe_max_it <= 0 || lit < o.wolfe_max_it) && a * o.wolfe_decrease >= o.wolfe_min_step) {
+            a = o.wolfe_decrease * a;
+            ++lit;
+            ++n;
+        }
+        return n;
+    }
+
+    int request_points() const { return stencil() * planned_trials(); }
 
     bool keep_going() const
     {
@@ -69,18 +97,27 @@ struct Machine {
         phase = MAIN;
     }
 
-    const double* centre() const { return phase == MAIN ? x : xn; }
-
-    // writes stencil() points of D doubles each
-    void emit(double* out) const
+    void emit_stencil(const double* c, double* out) const
     {
-        const double* c = centre();
         std::memcpy(out, c, sizeof(double) * D);
         for (int i = 0; i < 2 * D; ++i) {
             double* p = out + (size_t)(1 + i) * D;
             std::memcpy(p, c, sizeof(double) * D);
             if (i % 2 == 0) p[i / 2] += o.fd_eps / 2;
             else            p[i / 2] -= o.fd_eps / 2;
+        }
+    }
+
+    // writes request_points() points of D doubles each
+    void emit(double* out) const
+    {
+        if (phase == MAIN) { emit_stencil(x, out); return; }
+        const int n = planned_trials();
+        double a = alpha, c[10];
+        for (int t = 0; t < n; ++t) {
+            if (t > 0) a = o.wolfe_decrease * a;   // same recurrence as next_trial()
+            for (int k = 0; k < D; ++k) c[k] = x[k] - a * grad[k];
+            emit_stencil(c, out + (size_t)t * stencil() * D);
         }
     }
 
@@ -106,6 +143,8 @@ struct Machine {
 
     void finish_iteration()
     {
+        last_trials = ls_it;
+        first_request = true;
         for (int k = 0; k < D; ++k)
             step[k] = o.momentum * step[k] + (1 - o.momentum) * alpha * grad[k];
         step_len = std::sqrt(dot(step, step, D));
@@ -113,27 +152,40 @@ struct Machine {
         begin_iteration();
     }
 
-    // f holds stencil() objective values in emit() order
+    void gradient_of(const double* f, double* g) const
+    {
+        for (int k = 0; k < D; ++k) g[k] = (f[1 + 2 * k] - f[2 + 2 * k]) / o.fd_eps;
+    }
+
+    // f holds request_points() objective values in emit() order
     void feed(const double* f)
     {
-        n_evals += stencil();
         double g[10];
-        for (int k = 0; k < D; ++k) g[k] = (f[1 + 2 * k] - f[2 + 2 * k]) / o.fd_eps;
         if (phase == MAIN) {
+            n_evals += stencil();
+            gradient_of(f, g);
             fval = f[0];
             std::memcpy(grad, g, sizeof(double) * D);
             gg = dot(grad, grad, D);
             grad_len = std::sqrt(gg);
             alpha = o.wolfe_max_step / o.wolfe_decrease;
             ls_it = 0;
+            first_request = true;
             if (trial_allowed()) next_trial();
             else finish_iteration();
         } else if (phase == TRIAL) {
-            const bool armijo = f[0] <= fval - o.wolfe_c1 * alpha * gg;
-            const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
-            ++ls_it;
-            if (!(armijo && wolfe) && trial_allowed()) next_trial();
-            else finish_iteration();
+            const int n = planned_trials();
+            first_request = false;
+            for (int t = 0; t < n; ++t) {
+                const double* ft = f + (size_t)t * stencil();
+                n_evals += stencil();
+                gradient_of(ft, g);
+                const bool armijo = ft[0] <= fval - o.wolfe_c1 * alpha * gg;
+                const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
+                ++ls_it;
+                if (!(armijo && wolfe) && trial_allowed()) next_trial();
+                else { finish_iteration(); return; }
+            }
         }
     }
 
@@ -192,17 +244,22 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
     std::vector<Machine> ms(n_starts);
     for (int s = 0; s < n_starts; ++s) ms[s].start(dim, x0 + (size_t)s * dim, o);
 
-    const int S = 1 + 2 * dim;
     std::vector<double> pts, poses, planes, f;
     std::vector<int> active;
+    std::vector<size_t> offs;
     for (;;) {
         active.clear();
+        offs.clear();
+        size_t n = 0;
         for (int s = 0; s < n_starts; ++s)
-            if (ms[s].phase != Machine::DONE) active.push_back(s);
+            if (ms[s].phase != Machine::DONE) {
+                active.push_back(s);
+                offs.push_back(n);
+                n += (size_t)ms[s].request_points();
+            }
         if (active.empty()) break;
-        const size_t n = active.size() * (size_t)S;
         pts.resize(n * dim);
-        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].emit(pts.data() + a * S * dim);
+        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].emit(pts.data() + offs[a] * dim);
         poses.resize(n * 6);
         f.resize(n);
         const double* planes_ptr = nullptr;
@@ -219,7 +276,7 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), planes_ptr, f.data(), nullptr,
                                   nullptr);
         if (rc != CCAL_OK) return rc;
-        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + a * S);
+        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
     }
     for (int s = 0; s < n_starts; ++s) ms[s].result(&results[s]);
     return CCAL_OK;

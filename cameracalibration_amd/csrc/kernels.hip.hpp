@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void point_error_kernel(
 // (src/camera_calibration_optimization.cpp:305), and floating-point addition is
 // not associative, so the ordered sum (and the maximum) is the separate chain
 // pass below.
-constexpr int kMaxPosesPerPass = 32;
+constexpr int kMaxPosesPerPass = 64;
 
 __global__ __launch_bounds__(256) void exact_dist_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
