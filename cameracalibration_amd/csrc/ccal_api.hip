@@ -414,9 +414,9 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
     const CloudSet& cs = ctx->sets[which];
     const int C = cs.n_clouds;
 
-    // poses per pass: bounded by the distance buffer (8 B per pose and point)
-    const int64_t dist_budget = (int64_t)8 << 30;
-    int max_batch = (int)std::min<int64_t>(kMaxPosesPerPass, std::max<int64_t>(1, dist_budget / (8 * (int64_t)cs.total_pts)));
+    // one workgroup per (cloud, pose) chain; the batch bound only keeps the grid and the
+    // constant tables modest
+    const int max_batch = 4096;
     std::vector<double> mats, planes, hsum, hmax;
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
         const int nb = std::min(max_batch, n_poses - k0);
@@ -434,10 +434,11 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
             }
             // sqrt(pow(a,2)+pow(b,2)+pow(c,2)) as at :123 / :128
             pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+            pl[5] = 1.0 / pl[4];
+            pl[6] = (pl[4] > 0x1p-300 && pl[4] < 0x1p300) ? 1.0 : 0.0;
         }
         CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
         CCAL_HIP(ctx, ctx->planes_buf.ensure(planes.size() * sizeof(double)));
-        CCAL_HIP(ctx, ctx->dist_buf.ensure((size_t)pb * cs.total_pts * sizeof(double)));
         CCAL_HIP(ctx, ctx->osum_buf.ensure((size_t)pb * C * sizeof(double)));
         CCAL_HIP(ctx, ctx->omax_buf.ensure((size_t)pb * C * sizeof(double)));
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
@@ -445,24 +446,26 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, planes.data(),
                                      planes.size() * sizeof(double), hipMemcpyHostToDevice,
                                      ctx->stream));
-        hipLaunchKernelGGL(exact_dist_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
-                           cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                           cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
-                           ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
-                           ctx->dist_buf.as<double>());
-        const int n_chains = pb * C;
-        hipLaunchKernelGGL(ordered_sum_kernel, dim3(n_chains), dim3(64 * kChainWaves), 0,
-                           ctx->stream, ctx->dist_buf.as<double>(),
-                           cs.cloud_pt_off_dev.as<int64_t>(), n_chains, C,
-                           (int64_t)cs.total_pts, ctx->osum_buf.as<double>(),
-                           ctx->omax_buf.as<double>());
+        if (per_cloud_max)
+            hipLaunchKernelGGL(exact_chain_kernel<true>, dim3(pb * C), dim3(64 * kChainWaves), 0, ctx->stream,
+                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                               cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
+                               ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
+                               ctx->osum_buf.as<double>(), ctx->omax_buf.as<double>());
+        else
+            hipLaunchKernelGGL(exact_chain_kernel<false>, dim3(pb * C), dim3(64 * kChainWaves), 0, ctx->stream,
+                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                               cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
+                               ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
+                               ctx->osum_buf.as<double>(), (double*)nullptr);
         CCAL_HIP(ctx, hipGetLastError());
         hsum.resize((size_t)pb * C);
         hmax.resize((size_t)pb * C);
         CCAL_HIP(ctx, hipMemcpyAsync(hsum.data(), ctx->osum_buf.p, hsum.size() * sizeof(double),
                                      hipMemcpyDeviceToHost, ctx->stream));
-        CCAL_HIP(ctx, hipMemcpyAsync(hmax.data(), ctx->omax_buf.p, hmax.size() * sizeof(double),
-                                     hipMemcpyDeviceToHost, ctx->stream));
+        if (per_cloud_max)
+            CCAL_HIP(ctx, hipMemcpyAsync(hmax.data(), ctx->omax_buf.p, hmax.size() * sizeof(double),
+                                         hipMemcpyDeviceToHost, ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < nb; ++k) {
             double error = 0.0;
@@ -530,16 +533,12 @@ extern "C" int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, d
     if (!ctx) return CCAL_ERR_ARG;
     if (!out || (n && !values)) return fail(ctx, CCAL_ERR_ARG, "ordered_sum: null argument");
     if (int rc = bind(ctx)) return rc;
-    const int64_t off[2] = {0, (int64_t)n};
     CCAL_HIP(ctx, ctx->dist_buf.ensure(std::max<size_t>(n, 1) * sizeof(double)));
-    CCAL_HIP(ctx, ctx->tbl_buf.ensure(sizeof off));
     CCAL_HIP(ctx, ctx->osum_buf.ensure(sizeof(double)));
     CCAL_HIP(ctx, ctx->omax_buf.ensure(sizeof(double)));
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->dist_buf.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, off, sizeof off, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64 * kChainWaves), 0, ctx->stream, ctx->dist_buf.as<double>(),
-                       ctx->tbl_buf.as<int64_t>(), 1, 1, (int64_t)n, ctx->osum_buf.as<double>(),
-                       ctx->omax_buf.as<double>());
+                       (int64_t)n, ctx->osum_buf.as<double>(), ctx->omax_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
     CCAL_HIP(ctx, hipMemcpyAsync(out, ctx->osum_buf.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -634,7 +634,8 @@ struct BlockDesc {
 };
 
 // Per (pose, cloud): rows 0..2 of M = base_T_flange_j * F(pose), 12 doubles.
-// Per pose: plane a,b,c,d and sqrt(a^2+b^2+c^2), 5 doubles (padded to 8).
+// Per pose: plane a,b,c,d, sqrt(a^2+b^2+c^2), its rounded reciprocal and a flag
+// (non-zero when the norm is in the range the reciprocal path covers), padded to 8.
 constexpr int kPlaneStride = 8;
 
 __device__ inline double exact_distance(const double* M, const double* pl, float x, float y,
@@ -654,6 +655,39 @@ __device__ inline double exact_distance(const double* M, const double* pl, float
     // src/camera_calibration_optimization.cpp:121-129
     const double num = pl[0] * (double)q[0] + pl[1] * (double)q[1] + pl[2] * (double)q[2] + pl[3];
     return __builtin_fabs(num) / pl[4];
+}
+
+// a / b, correctly rounded, for b with a precomputed y = RN(1/b): two
+// Newton corrections with exact FMA residuals.  After the first, q1 is a
+// faithful rounding of a/b; with y within half an ulp of 1/b the second then
+// lands on RN(a/b) (Markstein, "Computation of elementary functions on the IBM
+// RISC System/6000 processor", 1990, theorem on q' = RN(q + r*y)).  The residuals
+// are exact only away from underflow and overflow, so callers take this path for
+// b in [2^-300, 2^300] and a zero or in [2^-600, 2^600] and divide otherwise.
+__device__ inline double divide_by_known(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-b, q0, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-b, q1, a);
+    return __builtin_fma(r1, y, q1);
+}
+
+// |a*qx + b*qy + c*qz + d| of exact_distance, before the division by the norm.
+__device__ inline double exact_numerator(const double* M, const double* pl, float x, float y, float z)
+{
+    const double xd = (double)x, yd = (double)y, zd = (double)z;
+    float q[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double p = M[r * 4 + 3];
+        p = xd * M[r * 4 + 0] + p;
+        p = yd * M[r * 4 + 1] + p;
+        p = zd * M[r * 4 + 2] + p;
+        q[r] = (float)p;
+    }
+    const double num = pl[0] * (double)q[0] + pl[1] * (double)q[1] + pl[2] * (double)q[2] + pl[3];
+    return __builtin_fabs(num);
 }
 
 // The viewer's plane-mode colouring (src/algorithms.cpp:379-385) transforms the point with
@@ -698,53 +732,12 @@ __global__ __launch_bounds__(256) void point_error_kernel(
     }
 }
 
-// Distances of every point for n_poses poses: dist[k][i] (pose-major, i = global
-// point index).  The sums are NOT formed here: the reference adds the distances
-// of a cloud one by one in point order
-// (src/camera_calibration_optimization.cpp:305), and floating-point addition is
-// not associative, so the ordered sum (and the maximum) is the separate chain
-// pass below.
-constexpr int kMaxPosesPerPass = 64;
-
-__global__ __launch_bounds__(256) void exact_dist_kernel(
-    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
-    const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
-    double* __restrict__ dist)
-{
-    __shared__ double sM[kMaxPosesPerPass * 12];
-    __shared__ double sP[kMaxPosesPerPass * kPlaneStride];
-    const BlockDesc bd = blocks[blockIdx.x];
-    for (int i = threadIdx.x; i < n_poses * 12; i += blockDim.x) {
-        int k = i / 12, e = i % 12;
-        sM[i] = mats[((int64_t)k * n_clouds + bd.cloud) * 12 + e];
-    }
-    for (int i = threadIdx.x; i < n_poses * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
-    __syncthreads();
-    for (int64_t i0 = bd.begin + threadIdx.x; i0 < bd.end; i0 += 4 * blockDim.x) {
-        float x[4], y[4], z[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t i = i0 + (int64_t)p * blockDim.x;
-            const bool in = i < bd.end;
-            x[p] = in ? xs[i] : 0.f; y[p] = in ? ys[i] : 0.f; z[p] = in ? zs[i] : 0.f;
-        }
-        for (int k = 0; k < n_poses; ++k) {
-            const double* M = sM + k * 12;
-            const double* pl = sP + k * kPlaneStride;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int64_t i = i0 + (int64_t)p * blockDim.x;
-                if (i < bd.end) dist[(int64_t)k * total_pts + i] = exact_distance(M, pl, x[p], y[p], z[p]);
-            }
-        }
-    }
-}
-
-// Ordered sum of one (pose k, cloud j) chain: average = ((0 + d_0) + d_1) + ... in
-// point order with a rounding after every add, exactly the reference's
-// accumulation -- computed by one workgroup per chain as an exact parallel
-// emulation of the sequential sum:
+// Ordered sum of one chain of non-negative values: ((0 + d_0) + d_1) + ... in
+// element order with a rounding after every add, exactly the reference's
+// accumulation of a cloud's distances
+// (src/camera_calibration_optimization.cpp:305; floating-point addition is not
+// associative, so a tree reduction would give other bits) -- computed by one
+// workgroup per chain as an exact parallel emulation of the sequential sum:
 //
 //   While the running sum s stays inside one binade [2^e, 2^(e+1)) every add
 //   rounds to a multiple of u = 2^(e-52).  With S = s/u (an integer in
@@ -752,142 +745,402 @@ __global__ __launch_bounds__(256) void exact_dist_kernel(
 //   even gives  S' = S + q + [r > 1/2]  and, only for an exact tie r == 1/2,
 //   S' = S + q + ((S + q) odd).  So an element is a map  parity(S) -> increment,
 //   and maps compose associatively:  (A then B)[p] = A[p] + B[(p + A[p]) & 1].
-//   Each lane folds 8 consecutive elements into its pair (inc[0], inc[1]), a
-//   wave composes its 64 pairs in lane order with a shuffle tree (one 512-element
-//   segment), and thread 0 applies the 16 segment maps of the workgroup in order
-//   to the actual S -- a segment is accepted iff S + total < 2^53, which (all
-//   increments being >= 0) holds exactly when no add inside it left the binade.
-//   The first rejected segment (about once per binade, ~20 times per chain) is
-//   replayed with plain one-by-one adds and the pass restarts behind it with the
-//   new binade; the first kChainWarm elements, where binades change every few
-//   adds, are summed one by one up front.
 //
-// Distances are >= 0 by construction.
+//   A pass covers W*512 consecutive elements: each lane folds its run of 8
+//   consecutive elements into a pair (inc[0], inc[1]), a wave forms the inclusive
+//   prefix composition of its 64 lane maps (one 512-element segment), and the
+//   first lanes of wave 0 compose the W segment maps and apply them to the
+//   actual S.  A prefix is valid iff S + increment < 2^53, which (all increments
+//   being >= 0) holds exactly when no add inside it left the binade.  At the
+//   first invalid prefix the owning wave finds the first lane whose run leaves
+//   the binade from its lane prefixes, that lane adds its 8 elements one by one
+//   in plain FP64 from the exact sum in front of it, and the rest of the pass is
+//   folded again with the new binade's unit (about once per binade, ~20 times
+//   per chain, most of them in the first pass where s doubles every few adds).
+//
+// The elements come from a source functor: the point-to-plane distances of one
+// (pose, cloud) pair computed on the fly from the SoA coordinates, or a plain
+// array.  Passes start at the chain's begin rounded down to a multiple of 8 so
+// that every lane's run is 32-byte aligned; elements outside [begin, end) count
+// as +0.0, which adds nothing.
+#ifndef CCAL_CHAIN_WAVES
+#define CCAL_CHAIN_WAVES 16
+#endif
 constexpr int kChainRun = 8;                       // consecutive elements per lane
 constexpr int kChainSeg = 64 * kChainRun;          // elements per wave segment
-constexpr int kChainWaves = 16;                    // segments per pass
-constexpr int kChainPass = kChainSeg * kChainWaves;
 
-__device__ inline void chain_fold(const double v[kChainRun], double scale, unsigned long long& inc0,
-                                  unsigned long long& inc1, bool& ok)
+// IEEE maxNum of two doubles as the single hardware instruction (a NaN operand
+// yields the other one).
+__device__ inline double max_f64(double a, double b)
 {
-    const double two53 = 9007199254740992.0;
-    inc0 = 0; inc1 = 0; ok = true;
-#pragma unroll
-    for (int t = 0; t < kChainRun; ++t) {
-        const double tt = v[t] * scale;             // exact (power of two)
-        ok = ok && (tt < two53);                    // also false for NaN
-        const double tc = tt < two53 ? tt : 0.0;
-        const unsigned long long q = (unsigned long long)tc;
-        const double r = tc - (double)q;            // exact
-        const unsigned long long up = r > 0.5 ? 1ull : 0ull;
-        const bool tie = r == 0.5;
-        inc0 += q + (tie ? ((inc0 + q) & 1ull) : up);
-        inc1 += q + (tie ? ((1ull + inc1 + q) & 1ull) : up);
-    }
-    // compose the 64 lane maps in lane order (left operand = lower lane)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long r0 = __shfl_down(inc0, off, 64);
-        const unsigned long long r1 = __shfl_down(inc1, off, 64);
-        inc0 += (inc0 & 1ull) ? r1 : r0;
-        inc1 += ((1ull + inc1) & 1ull) ? r1 : r0;
-    }
-    ok = __all(ok ? 1 : 0);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-// Also returns the chain's maximum (:306-307; order-free).
-__global__ __launch_bounds__(64 * kChainWaves) void ordered_sum_kernel(
-    const double* __restrict__ dist, const int64_t* __restrict__ cloud_pt_off, int n_chains,
-    int n_clouds, int64_t total_pts, double* __restrict__ out_sum, double* __restrict__ out_max)
+struct DistanceSource {
+    const float* xs; const float* ys; const float* zs;
+    int64_t limit;                                 // elements readable in xs/ys/zs
+    double M[12];
+    double pl[7];                                  // a, b, c, d, |n|, RN(1/|n|), range flag
+    struct Raw { float x[kChainRun], y[kChainRun], z[kChainRun]; };
+
+    __device__ inline Raw fetch(int64_t g0) const
+    {
+        Raw r;
+        if (g0 + kChainRun <= limit) {
+#pragma unroll
+            for (int h = 0; h < kChainRun / 4; ++h) {
+                const float4 a = *reinterpret_cast<const float4*>(xs + g0 + 4 * h);
+                const float4 b = *reinterpret_cast<const float4*>(ys + g0 + 4 * h);
+                const float4 c = *reinterpret_cast<const float4*>(zs + g0 + 4 * h);
+                r.x[4 * h] = a.x; r.x[4 * h + 1] = a.y; r.x[4 * h + 2] = a.z; r.x[4 * h + 3] = a.w;
+                r.y[4 * h] = b.x; r.y[4 * h + 1] = b.y; r.y[4 * h + 2] = b.z; r.y[4 * h + 3] = b.w;
+                r.z[4 * h] = c.x; r.z[4 * h + 1] = c.y; r.z[4 * h + 2] = c.z; r.z[4 * h + 3] = c.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < kChainRun; ++t) {
+                const bool in = g0 + t < limit;
+                r.x[t] = in ? xs[g0 + t] : 0.f; r.y[t] = in ? ys[g0 + t] : 0.f; r.z[t] = in ? zs[g0 + t] : 0.f;
+            }
+        }
+        return r;
+    }
+    // The run's distances; returns false if one of them is not an ordinary finite
+    // non-negative number.  pl[5] = RN(1/pl[4]) and pl[6] != 0 when pl[4] is in the
+    // range divide_by_known covers; numerators outside its range (zero included) send
+    // the whole run through the plain division.
+    __device__ inline bool values(const Raw& r, double d[kChainRun]) const
+    {
+        constexpr unsigned kLo = 0x1a700000u, kHi = 0x65700000u;   // high words of 2^-600, 2^600
+        double a[kChainRun];
+        unsigned hmin = 0xffffffffu, hmax = 0u;
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) {
+            a[t] = exact_numerator(M, pl, r.x[t], r.y[t], r.z[t]);
+            const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(a[t]) >> 32);
+            hmin = hi < hmin ? hi : hmin;
+            hmax = hi > hmax ? hi : hmax;
+            d[t] = divide_by_known(a[t], pl[4], pl[5]);
+        }
+        bool finite = true;
+        if (__builtin_expect(!(pl[6] != 0.0 && hmin >= kLo && hmax < kHi), 0)) {
+#pragma unroll
+            for (int t = 0; t < kChainRun; ++t) {
+                d[t] = a[t] / pl[4];
+                finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+            }
+        }
+        return finite;
+    }
+};
+
+struct ArraySource {
+    const double* v;
+    int64_t limit;
+    struct Raw { double d[kChainRun]; };
+    __device__ inline Raw fetch(int64_t g0) const
+    {
+        Raw r;
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) r.d[t] = g0 + t < limit ? v[g0 + t] : 0.0;
+        return r;
+    }
+    __device__ inline bool values(const Raw& r, double d[kChainRun]) const
+    {
+        bool finite = true;
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) {
+            d[t] = r.d[t];
+            finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+        }
+        return finite;
+    }
+};
+
+// a = (a then b) for parity maps
+__device__ inline void chain_compose(unsigned long long& a0, unsigned long long& a1,
+                                     unsigned long long b0, unsigned long long b1)
 {
-    __shared__ double sh_vals[kChainWaves][kChainSeg];   // this pass's elements (64 KiB)
-    __shared__ unsigned long long sh_inc[kChainWaves][2];
-    __shared__ int sh_ok[kChainWaves];
-    __shared__ double sh_red[kChainWaves];
+    const unsigned long long n0 = a0 + ((a0 & 1ull) ? b1 : b0);
+    const unsigned long long n1 = a1 + (((a1 + 1ull) & 1ull) ? b1 : b0);
+    a0 = n0;
+    a1 = n1;
+}
+
+// Inclusive prefix composition over the first N lanes of a wave (lower lane first).
+template <int N>
+__device__ inline void chain_scan(unsigned long long& i0, unsigned long long& i1, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < N; off <<= 1) {
+        unsigned long long l0 = __shfl_up(i0, off, 64);
+        unsigned long long l1 = __shfl_up(i1, off, 64);
+        chain_compose(l0, l1, i0, i1);
+        if (lane >= off) { i0 = l0; i1 = l1; }
+    }
+}
+
+// Composition of the 64 lane maps of a wave in lane order; valid in lane 0.
+__device__ inline void chain_compose_wave(unsigned long long& i0, unsigned long long& i1)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long r0 = __shfl_down(i0, off, 64);
+        const unsigned long long r1 = __shfl_down(i1, off, 64);
+        chain_compose(i0, i1, r0, r1);
+    }
+}
+
+// Map of one lane's run for the unit 1/scale (every element below 2^52 units).
+// n = RN-even(t) comes from adding 2^52 and reading the significand.  An element
+// that is not a tie adds n whatever the parity, so a run without ties is just the
+// sum of its n: one integer add per element, and `tie` stays false.  A tie
+// t = q + 1/2 has n = the even one of {q, q+1} and adds q + ((S + q) odd)
+// = n + parity(S) (t > n) or n - parity(S) (t < n); such runs are folded again
+// with both parities carried.
+__device__ inline void chain_fold_run(const double d[kChainRun], double scale, unsigned long long& inc0,
+                                      unsigned long long& inc1, bool& tie)
+{
+    const double two52 = 4503599627370496.0;
+    constexpr unsigned long long kBits52 = 0x4330000000000000ull;   // bit pattern of 2^52
+    unsigned long long sum = 0;
+    tie = false;
+#pragma unroll
+    for (int t = 0; t < kChainRun; ++t) {
+        const double tt = d[t] * scale;             // exact (power of two)
+        const double tm = tt + two52;               // in [2^52, 2^53]: the integer nearest to tt, ties to even
+        sum += (unsigned long long)__double_as_longlong(tm);
+        const double diff = tt - (tm - two52);      // both exact; in [-1/2, 1/2]
+        tie = tie || __builtin_fabs(diff) == 0.5;
+    }
+    sum -= (unsigned long long)kChainRun * kBits52;
+    inc0 = sum;
+    inc1 = sum;
+    if (__builtin_expect(tie, 0)) {
+        inc0 = 0; inc1 = 0;
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) {
+            const double tt = d[t] * scale;
+            const double tm = tt + two52;
+            const unsigned long long n = (unsigned long long)__double_as_longlong(tm) - kBits52;
+            const double diff = tt - (tm - two52);
+            const bool is_tie = __builtin_fabs(diff) == 0.5;
+            const unsigned long long sgn = diff > 0.0 ? 1ull : ~0ull;
+            inc0 += n + ((is_tie && (inc0 & 1ull)) ? sgn : 0ull);
+            inc1 += n + ((is_tie && ((inc1 + 1ull) & 1ull)) ? sgn : 0ull);
+        }
+    }
+}
+
+// Sum (ordered) and, if kWantMax, maximum (:306-307, order-free) of elements
+// [b, e) of src.  Every thread of the W-wave workgroup returns the same sum; the
+// maximum is valid in thread 0.
+template <int W, bool kWantMax, typename Source>
+__device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, double& out_sum, double& out_max)
+{
+    static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "W must be a power of two");
+    constexpr int kPass = kChainSeg * W;
+    constexpr unsigned long long kTwo53 = 1ull << 53;
+    const double two52 = 4503599627370496.0;
+    __shared__ unsigned long long sh_inc[W][2];
+    __shared__ int sh_ok[W];
+    __shared__ unsigned long long sh_S;
+    __shared__ int sh_adv;
     __shared__ double sh_s;
-    __shared__ int sh_first;
-    const int c = blockIdx.x;
-    if (c >= n_chains) return;
+    __shared__ int sh_consumed;
+    __shared__ double sh_red[W];
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = c / n_clouds, j = c % n_clouds;
-    const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
-    const double* row = dist + (int64_t)k * total_pts;
     const int my = wave * kChainSeg + lane * kChainRun;   // this lane's offset inside a pass
+    const int64_t b0 = b & ~(int64_t)(kChainRun - 1);
 
     double s = 0.0, mx = -1e9;                            // :288 error_mx = -1e9
-    double v[kChainRun], vn[kChainRun];
-#pragma unroll
-    for (int t = 0; t < kChainRun; ++t) v[t] = b + my + t < e ? row[b + my + t] : 0.0;   // a zero adds nothing
+    typename Source::Raw raw = src.fetch(b0 + my);
 
-    for (int64_t i = b; i < e; i += kChainPass) {
+    for (int64_t i = b0; i < e; i += kPass) {
         const int64_t left = e - i;
-        const int nseg = left >= kChainPass ? kChainWaves : (int)((left + kChainSeg - 1) / kChainSeg);
+        const int nelem = left >= kPass ? kPass : (int)left;
+        const int nseg = (nelem + kChainSeg - 1) / kChainSeg;
+        double d[kChainRun];
+        bool finite = src.values(raw, d);
+        if (!(i >= b && i + kPass <= e)) {
+            // first / last pass: elements outside [b, e) count as +0.0
+            finite = true;
+#pragma unroll
+            for (int t = 0; t < kChainRun; ++t) {
+                const int64_t g = i + my + t;
+                const bool in = g >= b && g < e;
+                d[t] = in ? d[t] : 0.0;
+                finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+                if (kWantMax && in) mx = d[t] > mx ? d[t] : mx;
+            }
+        }
+        double run_max = d[0];
+#pragma unroll
+        for (int t = 1; t < kChainRun; ++t) run_max = max_f64(run_max, d[t]);
+        if (kWantMax && i >= b && i + kPass <= e) mx = max_f64(mx, run_max);
         // next pass in flight while this one is folded
-#pragma unroll
-        for (int t = 0; t < kChainRun; ++t) {
-            const int64_t idx = i + kChainPass + my + t;
-            vn[t] = idx < e ? row[idx] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < kChainRun; ++t) {
-            sh_vals[wave][lane * kChainRun + t] = v[t];
-            if (i + my + t < e) mx = v[t] > mx ? v[t] : mx;
-        }
-        int first = 0;
+        if (i + kPass < e) raw = src.fetch(i + kPass + my);
+
+        int consumed = 0;                                 // elements of this pass already in s
         for (;;) {
             const unsigned long long sbits = (unsigned long long)__double_as_longlong(s);
-            const int ebiased = (int)((sbits >> 52) & 0x7ff);
+            const int ebiased = (int)(sbits >> 52);       // sign included: negative sums are not usable
             const bool usable = ebiased >= 64 && ebiased <= 2000;
+            if (!usable) {
+                // s is zero (or out of the range the units cover): the next run one by one
+                if (my == consumed) {
+                    double sv = s;
+#pragma unroll
+                    for (int t = 0; t < kChainRun; ++t) sv += d[t];
+                    sh_s = sv;
+                }
+                __syncthreads();
+                s = sh_s;
+                consumed += kChainRun;
+                __syncthreads();
+                if (consumed >= nelem) break;
+                continue;
+            }
             // scale = 1/u = 2^(52 - e): exponent field 1023 + 52 - (ebiased - 1023)
-            const double scale =
-                usable ? __longlong_as_double((long long)((unsigned long long)(2098 - ebiased) << 52)) : 1.0;
-            if (usable && wave >= first && wave < nseg) {
-                unsigned long long inc0, inc1;
-                bool ok;
-                chain_fold(v, scale, inc0, inc1, ok);
-                if (lane == 0) { sh_inc[wave][0] = inc0; sh_inc[wave][1] = inc1; sh_ok[wave] = ok ? 1 : 0; }
+            const double scale = __longlong_as_double((long long)((unsigned long long)(2098 - ebiased) << 52));
+            const double unit = __longlong_as_double((long long)((unsigned long long)(ebiased - 52) << 52));
+            // this lane's map; consumed lanes are the identity
+            unsigned long long inc0 = 0, inc1 = 0;
+            bool ok = true, tie = false;
+            const bool folding = (wave + 1) * kChainSeg > consumed && wave < nseg;
+            if (folding) {
+                if (my >= consumed) {
+                    ok = finite && run_max * scale < two52;
+                    if (ok) chain_fold_run(d, scale, inc0, inc1, tie);
+                }
+                unsigned long long t0 = inc0, t1 = inc1;
+                if (!__any(tie ? 1 : 0)) {
+                    // no ties in the segment: both parities add the plain sum
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) t0 += __shfl_xor(t0, off, 64);
+                    t1 = t0;
+                } else {
+                    chain_compose_wave(t0, t1);
+                }
+                const bool all_ok = __all(ok ? 1 : 0);
+                if (lane == 0) {
+                    // totals of 2^53 or more are rejected whatever their value: clamp so that
+                    // the composition over segments cannot wrap
+                    sh_inc[wave][0] = t0 < (kTwo53 << 1) ? t0 : (kTwo53 << 1);
+                    sh_inc[wave][1] = t1 < (kTwo53 << 1) ? t1 : (kTwo53 << 1);
+                    sh_ok[wave] = all_ok ? 1 : 0;
+                }
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                int adv = first;
-                double sn = s;
-                if (usable) {
-                    unsigned long long S = (unsigned long long)(s * scale);   // exact integer in [2^52, 2^53)
-                    for (; adv < nseg; ++adv) {
-                        const unsigned long long total = sh_inc[adv][S & 1ull];
-                        if (!sh_ok[adv] || total >= (1ull << 53) || S + total >= (1ull << 53)) break;
-                        S += total;
-                    }
-                    sn = (double)S / scale;                                  // exact
+            if (wave == 0) {
+                const int first_seg = consumed / kChainSeg;
+                const unsigned long long S = (unsigned long long)(s * scale);   // exact integer in [2^52, 2^53)
+                unsigned long long a0 = 0, a1 = 0;
+                bool seg_ok = true;
+                if (lane >= first_seg && lane < nseg) {
+                    a0 = sh_inc[lane][0]; a1 = sh_inc[lane][1]; seg_ok = sh_ok[lane] != 0;
                 }
-                if (adv < nseg) {
-                    // the segment that left the binade (or s not yet usable): one by one
-                    for (int t = 0; t < kChainSeg; ++t) sn += sh_vals[adv][t];
-                    ++adv;
+                chain_scan<W>(a0, a1, lane);
+                const unsigned long long tot = (S & 1ull) ? a1 : a0;
+                const bool bad = lane < nseg && (!seg_ok || S + tot >= kTwo53);
+                const unsigned long long mask = __ballot(bad ? 1 : 0);
+                const int adv = mask ? __builtin_ctzll(mask) : nseg;
+                const unsigned long long before = __shfl(tot, adv > 0 ? adv - 1 : 0, 64);
+                if (lane == 0) {
+                    sh_S = adv > 0 ? S + before : S;
+                    sh_adv = adv;
                 }
-                sh_s = sn;
-                sh_first = adv;
+            }
+            __syncthreads();
+            const int adv = sh_adv;
+            const unsigned long long Sx = sh_S;
+            if (adv >= nseg) {
+                s = (double)Sx * unit;                                       // exact
+                break;
+            }
+            if (wave == adv) {
+                // the run that leaves the binade (or cannot be folded): from the lane prefixes
+                chain_scan<64>(inc0, inc1, lane);
+                const unsigned long long tot = (Sx & 1ull) ? inc1 : inc0;
+                const bool bad = !ok || Sx + tot >= kTwo53;
+                const unsigned long long mask = __ballot(bad ? 1 : 0);
+                const int L = mask ? __builtin_ctzll(mask) : 63;             // mask is never empty here
+                const unsigned long long before = __shfl(tot, L > 0 ? L - 1 : 0, 64);
+                if (lane == L) {
+                    double sv = (double)(L > 0 ? Sx + before : Sx) * unit;   // exact
+#pragma unroll
+                    for (int t = 0; t < kChainRun; ++t) sv += d[t];
+                    sh_s = sv;
+                    sh_consumed = adv * kChainSeg + (L + 1) * kChainRun;
+                }
             }
             __syncthreads();
             s = sh_s;
-            first = sh_first;
-            if (first >= nseg) break;
+            consumed = sh_consumed;
+            if (consumed >= nelem) break;
         }
-#pragma unroll
-        for (int t = 0; t < kChainRun; ++t) v[t] = vn[t];
+    }
+    if (kWantMax) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const double om = __shfl_xor(mx, off, 64);
+            mx = om > mx ? om : mx;
+        }
+        if (lane == 0) sh_red[wave] = mx;
         __syncthreads();
+        if (threadIdx.x == 0)
+            for (int w = 1; w < W; ++w) mx = sh_red[w] > mx ? sh_red[w] : mx;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double om = __shfl_xor(mx, off, 64);
-        mx = om > mx ? om : mx;
-    }
-    if (lane == 0) sh_red[wave] = mx;
-    __syncthreads();
+    out_sum = s;
+    out_max = mx;
+}
+
+// Exact objective: one workgroup per (cloud j, pose k) chain; blocks of one cloud
+// are adjacent so that the poses of a batch stream the same coordinates through
+// the L2 caches together.  Results are stored pose-major: out[k * n_clouds + j];
+// out_max may be null when kWantMax is false.
+constexpr int kChainWaves = CCAL_CHAIN_WAVES;
+
+template <bool kWantMax>
+__global__ __launch_bounds__(64 * kChainWaves) void exact_chain_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const int64_t* __restrict__ cloud_pt_off, const double* __restrict__ mats,
+    const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
+    double* __restrict__ out_sum, double* __restrict__ out_max)
+{
+    const int j = blockIdx.x / n_poses, k = blockIdx.x % n_poses;
+    DistanceSource src;
+    src.xs = xs; src.ys = ys; src.zs = zs;
+    src.limit = total_pts;
+    const double* M = mats + ((int64_t)k * n_clouds + j) * 12;
+    const double* pl = planes + (int64_t)k * kPlaneStride;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) src.M[i] = M[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
+    double sum, mx;
+    chain_reduce<kChainWaves, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], sum, mx);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kChainWaves; ++w) mx = sh_red[w] > mx ? sh_red[w] : mx;
-        out_sum[c] = s;
-        out_max[c] = mx;
+        out_sum[(int64_t)k * n_clouds + j] = sum;
+        if (kWantMax) out_max[(int64_t)k * n_clouds + j] = mx;
+    }
+}
+
+// Ordered sum of a plain array of non-negative values (the accumulation primitive on
+// its own); a negative, infinite or NaN element is added one by one with its run.
+__global__ __launch_bounds__(64 * kChainWaves) void ordered_sum_kernel(
+    const double* __restrict__ values, int64_t n, double* __restrict__ out_sum, double* __restrict__ out_max)
+{
+    ArraySource src;
+    src.v = values;
+    src.limit = n;
+    double sum, mx;
+    chain_reduce<kChainWaves, true>(src, 0, n, sum, mx);
+    if (threadIdx.x == 0) {
+        out_sum[0] = sum;
+        out_max[0] = mx;
     }
 }
 
