@@ -401,6 +401,33 @@ extern "C" int ccal_get_plane(const ccal_ctx* ctx, float plane[4])
 // exact objective
 // ---------------------------------------------------------------------------
 
+template <int W, bool kWantMax>
+static void launch_exact_chains_w(ccal_ctx* ctx, const CloudSet& cs, int n_poses)
+{
+    hipLaunchKernelGGL((exact_chain_kernel<W, kWantMax>), dim3(n_poses * cs.n_clouds), dim3(64 * W), 0,
+                       ctx->stream, cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), n_poses, cs.n_clouds, (int64_t)cs.total_pts,
+                       ctx->osum_buf.as<double>(), kWantMax ? ctx->omax_buf.as<double>() : nullptr);
+}
+
+// Workgroup width by chain count (measured on 20 x 300k points: 16 waves win below ~128
+// chains, 8 up to ~512, 4 beyond).
+static void launch_exact_chains(ccal_ctx* ctx, const CloudSet& cs, int n_poses, bool want_max)
+{
+    const int64_t chains = (int64_t)n_poses * cs.n_clouds;
+    const int64_t per_cu = chains / std::max(1, ctx->n_cu);
+    if (want_max) {
+        if (per_cu < 1) launch_exact_chains_w<16, true>(ctx, cs, n_poses);
+        else if (per_cu < 2) launch_exact_chains_w<8, true>(ctx, cs, n_poses);
+        else launch_exact_chains_w<4, true>(ctx, cs, n_poses);
+    } else {
+        if (per_cu < 1) launch_exact_chains_w<16, false>(ctx, cs, n_poses);
+        else if (per_cu < 2) launch_exact_chains_w<8, false>(ctx, cs, n_poses);
+        else launch_exact_chains_w<4, false>(ctx, cs, n_poses);
+    }
+}
+
 int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
                      const double* planes4, double* cost, double* per_cloud_mean,
                      double* per_cloud_max)
@@ -446,18 +473,7 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, planes.data(),
                                      planes.size() * sizeof(double), hipMemcpyHostToDevice,
                                      ctx->stream));
-        if (per_cloud_max)
-            hipLaunchKernelGGL(exact_chain_kernel<true>, dim3(pb * C), dim3(64 * kChainWaves), 0, ctx->stream,
-                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                               cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
-                               ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
-                               ctx->osum_buf.as<double>(), ctx->omax_buf.as<double>());
-        else
-            hipLaunchKernelGGL(exact_chain_kernel<false>, dim3(pb * C), dim3(64 * kChainWaves), 0, ctx->stream,
-                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                               cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
-                               ctx->planes_buf.as<double>(), pb, C, (int64_t)cs.total_pts,
-                               ctx->osum_buf.as<double>(), (double*)nullptr);
+        launch_exact_chains(ctx, cs, pb, per_cloud_max != nullptr);
         CCAL_HIP(ctx, hipGetLastError());
         hsum.resize((size_t)pb * C);
         hmax.resize((size_t)pb * C);

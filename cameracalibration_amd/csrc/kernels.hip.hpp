@@ -763,9 +763,6 @@ __global__ __launch_bounds__(256) void point_error_kernel(
 // array.  Passes start at the chain's begin rounded down to a multiple of 8 so
 // that every lane's run is 32-byte aligned; elements outside [begin, end) count
 // as +0.0, which adds nothing.
-#ifndef CCAL_CHAIN_WAVES
-#define CCAL_CHAIN_WAVES 16
-#endif
 constexpr int kChainRun = 8;                       // consecutive elements per lane
 constexpr int kChainSeg = 64 * kChainRun;          // elements per wave segment
 
@@ -1100,11 +1097,11 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
 // Exact objective: one workgroup per (cloud j, pose k) chain; blocks of one cloud
 // are adjacent so that the poses of a batch stream the same coordinates through
 // the L2 caches together.  Results are stored pose-major: out[k * n_clouds + j];
-// out_max may be null when kWantMax is false.
-constexpr int kChainWaves = CCAL_CHAIN_WAVES;
-
-template <bool kWantMax>
-__global__ __launch_bounds__(64 * kChainWaves) void exact_chain_kernel(
+// out_max may be null when kWantMax is false.  W waves per workgroup: few chains want
+// many waves each (latency), many chains want small workgroups that overlap each
+// other's barriers and segment walks (throughput).
+template <int W, bool kWantMax>
+__global__ __launch_bounds__(64 * W) void exact_chain_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const int64_t* __restrict__ cloud_pt_off, const double* __restrict__ mats,
     const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
@@ -1121,7 +1118,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void exact_chain_kernel(
 #pragma unroll
     for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
     double sum, mx;
-    chain_reduce<kChainWaves, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], sum, mx);
+    chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], sum, mx);
     if (threadIdx.x == 0) {
         out_sum[(int64_t)k * n_clouds + j] = sum;
         if (kWantMax) out_max[(int64_t)k * n_clouds + j] = mx;
@@ -1130,6 +1127,8 @@ __global__ __launch_bounds__(64 * kChainWaves) void exact_chain_kernel(
 
 // Ordered sum of a plain array of non-negative values (the accumulation primitive on
 // its own); a negative, infinite or NaN element is added one by one with its run.
+constexpr int kChainWaves = 16;   // of the single-chain kernel
+
 __global__ __launch_bounds__(64 * kChainWaves) void ordered_sum_kernel(
     const double* __restrict__ values, int64_t n, double* __restrict__ out_sum, double* __restrict__ out_max)
 {
