@@ -26,6 +26,8 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -38,6 +40,8 @@ struct Machine {
     double fval = 0.0, grad_len = 0.0, step_len = 0.0;
     int it = 0;
     int64_t n_evals = 0;
+    int64_t n_requested = 0;   // evaluations asked of the device, dropped speculation included
+    int64_t n_requests = 0;
     // line search
     double alpha = 0.0, gg = 0.0, xn[10];
     int ls_it = 0;
@@ -53,6 +57,8 @@ struct Machine {
     int planned_trials() const
     {
         if (phase != TRIAL) return 1;
+        // a short request costs about as much as six wasted trials, and trial counts of
+        // consecutive iterations differ by a few: one spare trial measured best
         int want = first_request ? last_trials + 1 : 4;
         if (want > kMaxSpeculated) want = kMaxSpeculated;
         if (want < 1) want = 1;
@@ -161,6 +167,8 @@ struct Machine {
     void feed(const double* f)
     {
         double g[10];
+        n_requested += request_points();
+        ++n_requests;
         if (phase == MAIN) {
             n_evals += stencil();
             gradient_of(f, g);
@@ -278,6 +286,10 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         if (rc != CCAL_OK) return rc;
         for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
     }
+    if (std::getenv("CCAL_GD_STATS"))
+        for (int s = 0; s < n_starts; ++s)
+            std::fprintf(stderr, "gd[%d]: %lld evaluations used, %lld requested in %lld requests\n", s,
+                         (long long)ms[s].n_evals, (long long)ms[s].n_requested, (long long)ms[s].n_requests);
     for (int s = 0; s < n_starts; ++s) ms[s].result(&results[s]);
     return CCAL_OK;
 }

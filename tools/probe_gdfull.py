@@ -1,0 +1,11 @@
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import cameracalibration_amd as cc
+from cameracalibration_amd.synthetic import make_scene
+nc, npts = int(sys.argv[1]), int(sys.argv[2])
+s = make_scene(nc, npts)
+opt = cc.Optimizer(0)
+opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
+o = cc.GdOptions.default()
+t = time.time(); r = opt.gradient_descent(s.pose_init, o); print("gd", r.iterations, r.n_evals, r.fval, time.time() - t, flush=True)
