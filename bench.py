@@ -39,7 +39,10 @@ FLOP_PER_RESIDUAL = 8             # 4 mul + 3 add (K=4 dot) + 1 add into the run
 EXECUTED_FLOP_PER_RESIDUAL = {    # what the matrix pipe actually executes per residual
     "bf16x3": 2 * 32 + 1,         # one 16x16x32 bf16 MFMA per 256 residuals + the |.| add
     "f32": 2 * 4 + 1,             # one 16x16x4 f32 MFMA per 256 residuals + the |.| add
+    "bf16x3wide": 2 * 32 + 1,     # two 32x32x16 bf16 MFMAs per 1024 residuals + the |.| add
 }
+KERNEL_NAME = {"bf16x3": "residual_bf16x3_kernel", "f32": "residual_mfma_kernel",
+               "bf16x3wide": "residual_bf16x3_wide_kernel"}
 
 
 def hbm_traffic_per_launch(args):
@@ -66,7 +69,7 @@ def parse():
     ap.add_argument("--axis", type=int, default=10, help="grid steps per axis (10 -> 10^6 candidates)")
     ap.add_argument("--cpu-candidates", type=int, default=48,
                     help="candidates of the workload scored by the CPU oracle for cpu_baseline (0 = skip)")
-    ap.add_argument("--kernel", choices=["bf16x3", "f32"], default="bf16x3",
+    ap.add_argument("--kernel", choices=["bf16x3", "f32", "bf16x3wide"], default="bf16x3",
                     help="fast-path kernel: exact bf16x3 operand split on the bf16 matrix pipe, or FP32-input MFMA")
     ap.add_argument("--gd-iterations", type=int, default=-1,
                     help="iteration cap of the untimed GD refinement (-1 = reference's 10000, 0 = skip)")
@@ -114,7 +117,7 @@ def main():
     opt = cc.Optimizer(dev_index)
     opt.upload_clouds(cc.CCAL_DOWNSAMPLED, scene.clouds, scene.base_T_flange)
     opt.set_plane(scene.plane)
-    opt.set_fast_kernel(0 if args.kernel == "bf16x3" else 1)
+    opt.set_fast_kernel({"bf16x3": 0, "f32": 1, "bf16x3wide": 2}[args.kernel])
 
     n = args.axis
     counts = [n * world, n, n, n, n, n]
@@ -172,7 +175,7 @@ def main():
         "vs_baseline": None,
         # operands are FP32; the default kernel feeds them to the bf16 matrix pipe as an exact
         # three-way bf16 split and accumulates in FP32 (same 1e-5 tolerance as the FP32 kernel)
-        "dtype": "f32 (bf16x3 split operands, f32 accumulate)" if args.kernel == "bf16x3" else "f32",
+        "dtype": "f32" if args.kernel == "f32" else "f32 (bf16x3 split operands, f32 accumulate)",
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {args.clouds} poses x {args.points} pts/cloud, "
@@ -190,7 +193,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": ach_tflops / PEAK_FP32_TFLOPS,
             "traffic": hbm_traffic_per_launch(args),
-            "kernel": "residual_bf16x3_kernel" if args.kernel == "bf16x3" else "residual_mfma_kernel",
+            "kernel": KERNEL_NAME[args.kernel],
             "kernel_avg_ms": kernel_ms / max(launches, 1),
             "flop_per_residual": FLOP_PER_RESIDUAL,
             "note": "algorithmic FP32 work (8 FLOP/residual) against the FP32 peak, the yardstick of the task; "
@@ -198,10 +201,10 @@ def main():
             "matrix_pipe": {
                 "executed_flop_per_residual": EXECUTED_FLOP_PER_RESIDUAL[args.kernel],
                 "achieved": ach_tflops / FLOP_PER_RESIDUAL * EXECUTED_FLOP_PER_RESIDUAL[args.kernel],
-                "peak": PEAK_BF16_TFLOPS if args.kernel == "bf16x3" else PEAK_FP32_TFLOPS,
+                "peak": PEAK_FP32_TFLOPS if args.kernel == "f32" else PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach_tflops / FLOP_PER_RESIDUAL * EXECUTED_FLOP_PER_RESIDUAL[args.kernel]
-                        / (PEAK_BF16_TFLOPS if args.kernel == "bf16x3" else PEAK_FP32_TFLOPS),
+                        / (PEAK_FP32_TFLOPS if args.kernel == "f32" else PEAK_BF16_TFLOPS),
             },
         },
         "best_index": idx,

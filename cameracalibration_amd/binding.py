@@ -276,7 +276,7 @@ class Optimizer:
         return out
 
     def set_fast_kernel(self, kind: int) -> None:
-        """0 = bf16x3 split on the bf16 matrix pipe (default), 1 = FP32-input MFMA."""
+        """0 = bf16x3 split on the bf16 matrix pipe, 1 = FP32-input MFMA, 2 = bf16x3 as 32x32x16 pairs."""
         self._check(self._lib.ccal_set_fast_kernel(self._ctx, int(kind)))
 
     def set_plane(self, plane: Sequence[float]) -> None:

@@ -113,6 +113,20 @@ FoldConsts fold_consts(const float plane[4])
     return fc;
 }
 
+// The points as ready-made bf16x3 operands of the wide residual kernel (64 B per point
+// instead of 16): built on first use of that kernel only.
+int ensure_split_groups(ccal_ctx* ctx, CloudSet& cs)
+{
+    if (cs.split_ready) return CCAL_OK;
+    CCAL_HIP(ctx, cs.split_groups.ensure((size_t)cs.n_groups * 256 * sizeof(u32x4)));
+    hipLaunchKernelGGL(split_groups_kernel, dim3((unsigned)cs.n_groups), dim3(256), 0, ctx->stream,
+                       cs.groups.as<f32x4>(), cs.n_groups, cs.split_groups.as<u32x4>());
+    CCAL_HIP(ctx, hipGetLastError());
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    cs.split_ready = true;
+    return CCAL_OK;
+}
+
 // wgen + residual + split reduction for one chunk of candidates; costs go to
 // cost_dst[0..n).  ev0/ev1 (optional) bracket the residual kernel.
 template <typename Source>
@@ -128,7 +142,13 @@ int run_fast_chunk(ccal_ctx* ctx, const CloudSet& cs, const Source& src, int64_t
                        cs.base_dev.as<double>(), cs.centres_dev.as<double>(), fc,
                        ctx->w_buf.as<float>());
     if (ev0) CCAL_HIP(ctx, hipEventRecord(ev0, ctx->stream));
-    if (ctx->fast_kernel == 1)
+    if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)
+        hipLaunchKernelGGL(residual_bf16x3_wide_kernel<kNA / 2>, dim3((unsigned)f.cand_blocks, f.n_splits),
+                           dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
+                           cs.split_groups.as<u32x4>(), cs.group_off_dev.as<int>(),
+                           cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
+                           f.n_ctiles, f.n_splits);
+    else if (ctx->fast_kernel == CCAL_FAST_F32)
         hipLaunchKernelGGL(residual_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
                            dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
                            cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
@@ -357,6 +377,9 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, cs.centres_dev.ensure(3 * n_clouds * sizeof(double)));
     CCAL_HIP(ctx, cs.base_dev.ensure(16 * (size_t)n_clouds * sizeof(double)));
     CCAL_HIP(ctx, hipMemcpy(cs.groups.p, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice));
+    cs.split_ready = false;
+    if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)
+        if (int rc = ensure_split_groups(ctx, cs)) return rc;
     CCAL_HIP(ctx, hipMemcpy(cs.group_off_dev.p, cs.group_off.data(), (n_clouds + 1) * sizeof(int),
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.scale_dev.p, scale.data(), n_clouds * sizeof(double),
@@ -372,9 +395,16 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
 extern "C" int ccal_set_fast_kernel(ccal_ctx* ctx, int kind)
 {
     if (!ctx) return CCAL_ERR_ARG;
-    if (kind != CCAL_FAST_BF16X3 && kind != CCAL_FAST_F32)
-        return fail(ctx, CCAL_ERR_ARG, "set_fast_kernel: kind must be CCAL_FAST_BF16X3 or CCAL_FAST_F32");
+    if (kind != CCAL_FAST_BF16X3 && kind != CCAL_FAST_F32 && kind != CCAL_FAST_BF16X3_WIDE)
+        return fail(ctx, CCAL_ERR_ARG,
+                    "set_fast_kernel: kind must be CCAL_FAST_BF16X3, CCAL_FAST_F32 or CCAL_FAST_BF16X3_WIDE");
     ctx->fast_kernel = kind;
+    if (kind == CCAL_FAST_BF16X3_WIDE) {
+        if (int rc = bind(ctx)) return rc;
+        for (CloudSet& cs : ctx->sets)
+            if (cs.ready)
+                if (int rc = ensure_split_groups(ctx, cs)) return rc;
+    }
     return CCAL_OK;
 }
 

@@ -50,6 +50,8 @@ struct CloudSet {
 
     // fast path: centred 64-point groups
     DevBuf groups, group_off_dev, scale_dev, centres_dev, base_dev;
+    DevBuf split_groups;               // bf16x3 K-slot form of `groups` for the wide kernel
+    bool split_ready = false;          // built on first selection of that kernel
     std::vector<int> group_off;        // n_clouds + 1
     std::vector<double> centres;       // n_clouds * 3
     int64_t n_groups = 0;
@@ -60,7 +62,7 @@ struct CloudSet {
     {
         xs.release(); ys.release(); zs.release(); blocks.release();
         cloud_block_off_dev.release(); cloud_pt_off_dev.release(); groups.release(); group_off_dev.release();
-        scale_dev.release(); centres_dev.release(); base_dev.release();
+        scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release();
         ready = false;
     }
 };

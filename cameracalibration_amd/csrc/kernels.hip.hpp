@@ -452,6 +452,223 @@ __global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Wide form of the bf16x3 kernel: v_mfma_f32_32x32x16_bf16 pairs
+// ---------------------------------------------------------------------------
+// Every MFMA keeps the VALU port closed for ~8-10 cycles whatever its size, and
+// one |d| add per residual and lane is irreducible, so the 16x16x32 form pays one
+// MFMA issue per 4 adds.  A 32x32x16 MFMA covers 32 candidates x 32 points with
+// K = 16, two chained ones (x|y slots, then z|constant slots) give the same
+// K = 32 contraction for 1024 residuals: one MFMA issue per 8 adds.  The point
+// operands are split once, at upload, into their bf16x3 K-slot form
+// (split_groups_kernel), so the kernel loads them ready-made (64 B per point
+// instead of 16; the stream stays L2-resident per candidate block as before).
+//
+// Operand layout of v_mfma_f32_32x32x16_bf16: lane l supplies row/column l&31 and
+// the eight K-slots 8*(l>>5)..+7.  First MFMA: lanes 0-31 carry coordinate x,
+// lanes 32-63 coordinate y; second: z and the constant.  The result puts point
+// column l&31 and candidate rows 8*(i/4) + 4*(l>>5) + i%4 (i = 0..15) in lane l.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kFlushTiles32 = 128;  // FP32 partial sums are promoted every 128 adds
+
+// bq[((tile32 * 2 + h) * 64 + lane]: operand h of the 32-point tile, tile32 = 2*group + s.
+__global__ __launch_bounds__(256) void split_groups_kernel(const f32x4* __restrict__ groups,
+                                                            int64_t n_groups, u32x4* __restrict__ bq)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_groups * 256) return;
+    const int lane = (int)(idx & 63), h = (int)((idx >> 6) & 1), s = (int)((idx >> 7) & 1);
+    const int64_t g = idx >> 8;
+    const int n = lane & 31, k = 2 * h + (lane >> 5);
+    const int u = 2 * s + (n >> 4), col = n & 15;
+    const f32x4 src = groups[g * 64 + k * 16 + col];
+    bq[idx] = __builtin_bit_cast(u32x4, split_point_operand(src[u]));
+}
+
+// Promotes the FP32 lane accumulators (64 per lane: tile a, register i) into two
+// FP64 totals per lane by a reduce-scatter over the 32 point columns of each lane
+// half (5 exchange steps); afterwards lane column n owns values 2n and 2n+1,
+// value = a*16 + i.
+template <int NA>
+__device__ inline void promote_wide(float (&acc)[NA][16], double scale, double& tot0, double& tot1)
+{
+    static_assert(NA == 4, "the reduce-scatter below is written for 64 values per lane");
+    const int n = threadIdx.x & 31;
+    float v[64];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[a * 16 + i] = acc[a][i]; acc[a][i] = 0.f; }
+    float w32[32];
+    {
+        const bool hi = (n & 16) != 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float keep = hi ? v[32 + i] : v[i];
+            const float give = hi ? v[i] : v[32 + i];
+            w32[i] = keep + __shfl_xor(give, 16, 64);
+        }
+    }
+    float w16[16];
+    {
+        const bool hi = (n & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float keep = hi ? w32[16 + i] : w32[i];
+            const float give = hi ? w32[i] : w32[16 + i];
+            w16[i] = keep + __shfl_xor(give, 8, 64);
+        }
+    }
+    float w8[8];
+    {
+        const bool hi = (n & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float keep = hi ? w16[8 + i] : w16[i];
+            const float give = hi ? w16[i] : w16[8 + i];
+            w8[i] = keep + __shfl_xor(give, 4, 64);
+        }
+    }
+    float w4[4];
+    {
+        const bool hi = (n & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = hi ? w8[4 + i] : w8[i];
+            const float give = hi ? w8[i] : w8[4 + i];
+            w4[i] = keep + __shfl_xor(give, 2, 64);
+        }
+    }
+    {
+        const bool hi = (n & 1) != 0;
+        const float k0 = hi ? w4[2] : w4[0], g0 = hi ? w4[0] : w4[2];
+        const float k1 = hi ? w4[3] : w4[1], g1 = hi ? w4[1] : w4[3];
+        tot0 += (double)(k0 + __shfl_xor(g0, 1, 64)) * scale;
+        tot1 += (double)(k1 + __shfl_xor(g1, 1, 64)) * scale;
+    }
+}
+
+// grid = (candidate blocks of 512, point splits); block = 4 waves; wave w of block
+// bx owns the NA 32-candidate tiles starting at candidate (bx*4 + w) * 32 * NA.
+// W is the 16-wide tile layout of wgen_kernel (n_ctiles16 tiles per cloud).
+template <int NA>
+__global__ __launch_bounds__(256, 3) void residual_bf16x3_wide_kernel(
+    const float* __restrict__ W, const u32x4* __restrict__ bq,
+    const int* __restrict__ group_off, const double* __restrict__ scale,
+    double* __restrict__ partial, int n_clouds, int n_ctiles16, int n_splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int m = lane & 31, half = lane >> 5;
+    const int ct32_0 = (blockIdx.x * 4 + wave) * NA;
+    const int split = blockIdx.y;
+    __shared__ u32x4 stage[2][4 * 2 * 64];   // two stages of four tiles x two operands (16 KiB)
+    f32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+    double tot0 = 0.0, tot1 = 0.0;
+
+    for (int j = 0; j < n_clouds; ++j) {
+        const int g0 = group_off[j];
+        const int G = group_off[j + 1] - g0;
+        const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
+        const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
+        if (gb >= ge) continue;
+        bf16x8 A1[NA], A2[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int ct16 = (ct32_0 + a) * 2 + (m >> 4);
+            const float* w = W + ((int64_t)j * n_ctiles16 + ct16) * 64 + (m & 15);
+            A1[a] = split_candidate_operand(w[half * 16], false);
+            A2[a] = split_candidate_operand(w[(2 + half) * 16], half == 1);
+        }
+        const double sc = scale[j];
+
+        float acc[NA][16];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+
+        // Stages of four 32-point tiles go through LDS: wave w fetches tile w of the next
+        // stage from global memory while all four waves contract the current stage, so the
+        // L2 sees every operand once per workgroup instead of once per wave.
+        const int t_begin = 2 * gb, n_tiles = 2 * (ge - gb);
+        const int n_stages = (n_tiles + 3) / 4;
+        {
+            const int t = wave;
+            if (t < n_tiles) {
+                const u32x4* src = bq + ((int64_t)(t_begin + t) * 2) * 64 + lane;
+                stage[0][(wave * 2 + 0) * 64 + lane] = src[0];
+                stage[0][(wave * 2 + 1) * 64 + lane] = src[64];
+            }
+        }
+        __syncthreads();
+        f32x16 carry = zero;
+        int since = 0;
+        for (int st = 0; st < n_stages; ++st) {
+            const int t_next = 4 * (st + 1) + wave;
+            const bool have_next = t_next < n_tiles;
+            u32x4 g1 = {0u, 0u, 0u, 0u}, g2 = {0u, 0u, 0u, 0u};
+            if (have_next) {
+                const u32x4* src = bq + ((int64_t)(t_begin + t_next) * 2) * 64 + lane;
+                g1 = src[0];
+                g2 = src[64];
+            }
+            const u32x4* buf = stage[st & 1] + lane;
+            const int tiles_here = n_tiles - 4 * st < 4 ? n_tiles - 4 * st : 4;
+            u32x4 b1 = buf[0], b2 = buf[64];
+            for (int tt = 0; tt < tiles_here; ++tt) {
+                u32x4 n1 = b1, n2 = b2;
+                if (tt + 1 < tiles_here) { n1 = buf[(tt + 1) * 128]; n2 = buf[(tt + 1) * 128 + 64]; }
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, b1);
+                const bf16x8 B2 = __builtin_bit_cast(bf16x8, b2);
+                f32x16 d[NA];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    const f32x16 done = a == 0 ? carry : d[a == 0 ? 0 : a - 1];
+                    const int pa = (a + NA - 1) % NA;
+                    d[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[a], B1, zero, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[pa][i] += __builtin_fabsf(done[i]);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    d[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[a], B2, d[a], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                    for (int i = 8; i < 16; ++i) acc[pa][i] += __builtin_fabsf(done[i]);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                carry = d[NA - 1];
+                b1 = n1;
+                b2 = n2;
+                if (++since == kFlushTiles32) {
+                    since = 0;
+                    promote_wide<NA>(acc, sc, tot0, tot1);
+                }
+            }
+            if (have_next) {
+                stage[(st + 1) & 1][(wave * 2 + 0) * 64 + lane] = g1;
+                stage[(st + 1) & 1][(wave * 2 + 1) * 64 + lane] = g2;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[NA - 1][i] += __builtin_fabsf(carry[i]);
+        promote_wide<NA>(acc, sc, tot0, tot1);
+    }
+
+    // lane (half, column n) owns values 2n and 2n+1: tile a = value >> 4, register i = value & 15
+    double* out = partial + (int64_t)split * n_ctiles16 * 16;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int value = 2 * m + which;
+        const int a = value >> 4, i = value & 15;
+        const int row = 8 * (i >> 2) + 4 * half + (i & 3);
+        out[(int64_t)(ct32_0 + a) * 32 + row] = which ? tot1 : tot0;
+    }
+}
+
 // Same contraction, counting |w.p| < thr instead of summing (RANSAC scoring).
 // Padding points have residual 0 and are counted; the host subtracts them.
 template <int NA>

@@ -123,10 +123,12 @@ int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* pose
 /* Which kernel the fast path runs (no counterpart in the reference):
  *   CCAL_FAST_BF16X3 (default)  operands split exactly into three bf16 pieces,
  *                               contraction on the bf16 matrix pipe, FP32 accumulate;
- *   CCAL_FAST_F32               FP32-input matrix instruction (fmaf-chain exact).
- * Both meet the same 1e-5 cost tolerance; the final arg-min never depends on it
+ *   CCAL_FAST_F32               FP32-input matrix instruction (fmaf-chain exact);
+ *   CCAL_FAST_BF16X3_WIDE       the bf16x3 contraction as pairs of 32x32x16 matrix
+ *                               instructions on point operands split at upload.
+ * All meet the same 1e-5 cost tolerance; the final arg-min never depends on it
  * (near-minimum candidates are re-scored with ccal_eval arithmetic). */
-enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1 };
+enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1, CCAL_FAST_BF16X3_WIDE = 2 };
 int ccal_set_fast_kernel(ccal_ctx* ctx, int kind);
 
 /* Candidate grid of discreteCombinatorialOptimization (:526-558), generalised:

@@ -172,9 +172,10 @@ def test_exact_eval_with_caller_planes(gpu_opt, oracle):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("kind", [0, 1])
-def test_both_fast_kernels_meet_tolerance(gpu_opt, oracle, kind):
-    """kind 0: exact bf16x3 operand split on the bf16 matrix pipe; kind 1: FP32-input MFMA."""
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_every_fast_kernel_meets_tolerance(gpu_opt, oracle, kind):
+    """kind 0: exact bf16x3 operand split on the bf16 matrix pipe; kind 1: FP32-input MFMA;
+    kind 2: the bf16x3 contraction as 32x32x16 pairs on operands split at upload."""
     s = make_scene(7, 9000, seed=55, ragged=True)
     upload(gpu_opt, s)
     gpu_opt.set_fast_kernel(kind)
