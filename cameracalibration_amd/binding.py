@@ -140,6 +140,7 @@ SIGNATURES = {
     "ccal_eval_fast": (C.c_int, [_CTX, C.c_int, C.c_int64, _D, _F]),
     "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
     "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
+    "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
     "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
     "ccal_write_config": (C.c_int, [C.c_char_p, C.c_char_p, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
@@ -149,6 +150,7 @@ SIGNATURES = {
         C.c_int,
         [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _P(C.c_int64), _D, _D, _P(GridStats)],
     ),
+    "ccal_grid_costs": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _F]),
     "ccal_argmin_merge": (C.c_int, [C.c_int, _D, _P(C.c_int64)]),
     "ccal_fit_plane_lsq": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_ransac_plane": (
@@ -279,6 +281,10 @@ class Optimizer:
         """0 = bf16x3 split on the bf16 matrix pipe, 1 = FP32-input MFMA, 2 = bf16x3 as 32x32x16 pairs."""
         self._check(self._lib.ccal_set_fast_kernel(self._ctx, int(kind)))
 
+    def set_search_mode(self, mode: int) -> None:
+        """0 = dense (every residual on the matrix cores), 1 = separable (one histogram pass per rotation)."""
+        self._check(self._lib.ccal_set_search_mode(self._ctx, int(mode)))
+
     def set_plane(self, plane: Sequence[float]) -> None:
         p = np.ascontiguousarray(plane, dtype=np.float32)
         self._check(self._lib.ccal_set_plane(self._ctx, p.ctypes.data_as(_F)))
@@ -367,6 +373,18 @@ class Optimizer:
             )
         )
         return int(idx.value), float(cost.value), pose, st
+
+    def grid_costs(self, base_pose, grid: Optional[Grid] = None, begin: int = 0,
+                   end: Optional[int] = None, which: int = CCAL_DOWNSAMPLED) -> np.ndarray:
+        """Fast-path cost of every candidate of [begin,end) in the current search mode."""
+        g = grid if grid is not None else Grid.default()
+        if end is None:
+            end = g.size
+        b = np.ascontiguousarray(base_pose, dtype=np.float64)
+        out = np.empty(int(end) - int(begin), dtype=np.float32)
+        self._check(self._lib.ccal_grid_costs(self._ctx, which, _dptr(b), C.byref(g), int(begin), int(end),
+                                              out.ctypes.data_as(_F)))
+        return out
 
     def fit_plane(self, pose, which: int = CCAL_RAW) -> np.ndarray:
         p = np.ascontiguousarray(pose, dtype=np.float64)

@@ -225,7 +225,8 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     DevBuf* bufs[] = {&ctx->w_buf, &ctx->partial_buf, &ctx->cost_buf, &ctx->rec_buf,
                       &ctx->minrec_buf, &ctx->list_buf, &ctx->count_buf, &ctx->mats_buf,
                       &ctx->planes_buf, &ctx->psum_buf, &ctx->pmax_buf, &ctx->osum_buf,
-                      &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf};
+                      &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf, &ctx->sep_wr,
+                      &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta};
     for (DevBuf* b : bufs) b->release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -405,6 +406,15 @@ extern "C" int ccal_set_fast_kernel(ccal_ctx* ctx, int kind)
             if (cs.ready)
                 if (int rc = ensure_split_groups(ctx, cs)) return rc;
     }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_search_mode(ccal_ctx* ctx, int mode)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (mode != CCAL_SEARCH_DENSE && mode != CCAL_SEARCH_SEPARABLE)
+        return fail(ctx, CCAL_ERR_ARG, "set_search_mode: mode must be CCAL_SEARCH_DENSE or CCAL_SEARCH_SEPARABLE");
+    ctx->search_mode = mode;
     return CCAL_OK;
 }
 
@@ -682,27 +692,175 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
     return best;
 }
 
-extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
-                                const ccal_grid* g, int64_t begin, int64_t end,
-                                int64_t* best_index, double* best_cost, double best_pose[6],
-                                ccal_grid_stats* stats)
+// ---------------------------------------------------------------------------
+// separable search: all translations of a rotation from one pass over the points
+// ---------------------------------------------------------------------------
+constexpr int kSepTC = 1024;  // translations per launch (histogram bins in LDS)
+constexpr int kSepRB = 4;     // rotations per workgroup
+
+// Fast-path costs of translations [t0, t1) x all R rotations of the grid into
+// cost[(t - t0) * R + r] (device).  kernel_ms accumulates the histogram kernel's time.
+static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6], const ccal_grid* g,
+                         int64_t t0, int64_t t1, float* cost, double* kernel_ms, int* launches)
 {
-    if (int rc = check_set(ctx, which)) return rc;
-    if (!base_pose || !g || !best_index || !best_cost || !best_pose)
-        return fail(ctx, CCAL_ERR_ARG, "grid_search: null argument");
-    if (!ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "grid_search: plane not set");
-    const int64_t total = ccal_grid_size(g);
-    if (total <= 0) return fail(ctx, CCAL_ERR_ARG, "grid_search: empty grid axis");
-    if (begin < 0 || end > total || begin > end)
-        return fail(ctx, CCAL_ERR_ARG, "grid_search: candidate range outside the grid");
-    if (stats) std::memset(stats, 0, sizeof *stats);
-    *best_index = -1;
-    *best_cost = 1e9;  // :531
-    std::memcpy(best_pose, base_pose, 6 * sizeof(double));
+    const int C = cs.n_clouds;
+    const int n3 = g->count[3], n4 = g->count[4], n5 = g->count[5];
+    const int64_t R = (int64_t)n3 * n4 * n5;
+    const FoldConsts fc = fold_consts(ctx->plane);
+
+    // per cloud: g_j = R_j^T n and h_j = n.b_j + d (the pose-independent parts of the fold)
+    std::vector<double> gj((size_t)3 * C), hj(C);
+    for (int j = 0; j < C; ++j) {
+        const double* B = cs.base_T_flange.data() + 16 * (size_t)j;
+        for (int k = 0; k < 3; ++k) gj[3 * j + k] = fc.n[0] * B[k] + fc.n[1] * B[4 + k] + fc.n[2] * B[8 + k];
+        hj[j] = fc.n[0] * B[3] + fc.n[1] * B[7] + fc.n[2] * B[11] + fc.d;
+    }
+    auto translation = [&](int64_t t, double tf[3]) {
+        const int i2 = (int)(t % g->count[2]); t /= g->count[2];
+        const int i1 = (int)(t % g->count[1]); t /= g->count[1];
+        tf[0] = grid_axis_value(g, base, 0, (int)t);
+        tf[1] = grid_axis_value(g, base, 1, i1);
+        tf[2] = grid_axis_value(g, base, 2, i2);
+    };
+    auto b_of = [&](int j, const double tf[3]) {
+        return (gj[3 * j] * tf[0] + gj[3 * j + 1] * tf[1] + gj[3 * j + 2] * tf[2] + hj[j]) * fc.inv_norm;
+    };
+    // reference constant per cloud: the middle translation of the whole range
+    std::vector<double> bref(C);
+    {
+        double tf[3];
+        translation((t0 + t1) / 2, tf);
+        for (int j = 0; j < C; ++j) bref[j] = b_of(j, tf);
+    }
+
+    // rotation vectors: w123 = R_F^T g_j / |n|, a = w123.c_j + bref_j
+    std::vector<float> wr((size_t)R * C * 4);
+    {
+        std::vector<double> sn[3], cn[3];
+        for (int k = 0; k < 3; ++k) {
+            sn[k].resize(g->count[3 + k]);
+            cn[k].resize(g->count[3 + k]);
+            for (int i = 0; i < g->count[3 + k]; ++i) {
+                const double a = grid_axis_value(g, base, 3 + k, i);
+                sn[k][i] = std::sin(a);
+                cn[k][i] = std::cos(a);
+            }
+        }
+        for (int64_t r = 0; r < R; ++r) {
+            const int i5 = (int)(r % n5), i4 = (int)((r / n5) % n4), i3 = (int)(r / ((int64_t)n5 * n4));
+            const double s[3] = {sn[0][i3], sn[1][i4], sn[2][i5]}, c[3] = {cn[0][i3], cn[1][i4], cn[2][i5]};
+            double RF[9];
+            rotation_zyx(s, c, RF);
+            for (int j = 0; j < C; ++j) {
+                double w[3];
+                for (int k = 0; k < 3; ++k)
+                    w[k] = (gj[3 * j] * RF[k] + gj[3 * j + 1] * RF[3 + k] + gj[3 * j + 2] * RF[6 + k]) * fc.inv_norm;
+                const double a = w[0] * cs.centres[3 * j] + w[1] * cs.centres[3 * j + 1] +
+                                 w[2] * cs.centres[3 * j + 2] + bref[j];
+                float* dst = wr.data() + ((size_t)r * C + j) * 4;
+                dst[0] = (float)w[0]; dst[1] = (float)w[1]; dst[2] = (float)w[2]; dst[3] = (float)a;
+            }
+        }
+    }
+    CCAL_HIP(ctx, ctx->sep_wr.ensure(wr.size() * sizeof(float)));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->sep_wr.p, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice,
+                                 ctx->stream));
+
+    constexpr int M = 2 * kSepTC;
+    std::vector<float> sb;
+    std::vector<int> perm;
+    std::vector<unsigned short> tab;
+    std::vector<SepMeta> meta(C);
+    std::vector<std::pair<float, int>> order;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    CCAL_HIP(ctx, hipEventCreate(&e0));
+    CCAL_HIP(ctx, hipEventCreate(&e1));
+    int rc = CCAL_OK;
+    for (int64_t ta = t0; ta < t1 && rc == CCAL_OK; ta += kSepTC) {
+        const int nt = (int)std::min<int64_t>(kSepTC, t1 - ta);
+        sb.assign((size_t)C * nt, 0.f);
+        perm.assign((size_t)C * nt, 0);
+        tab.assign((size_t)C * (M + 1), 0);
+        for (int j = 0; j < C; ++j) {
+            order.resize(nt);
+            for (int tl = 0; tl < nt; ++tl) {
+                double tf[3];
+                translation(ta + tl, tf);
+                order[tl] = {(float)(b_of(j, tf) - bref[j]), tl};
+            }
+            std::sort(order.begin(), order.end());
+            for (int q = 0; q < nt; ++q) {
+                sb[(size_t)j * nt + q] = order[q].first;
+                perm[(size_t)j * nt + q] = order[q].second;
+            }
+            const float bmin = order.front().first, bmax = order.back().first;
+            const double delta = bmax > bmin ? ((double)bmax - (double)bmin) / M : 1.0;
+            meta[j].bmin = bmin;
+            meta[j].inv_delta = (float)(1.0 / delta);
+            unsigned short* tj = tab.data() + (size_t)j * (M + 1);
+            int q = 0;
+            for (int m = 0; m <= M; ++m) {
+                const double edge = (double)bmin + m * delta;
+                while (q < nt && (double)order[q].first < edge) ++q;
+                tj[m] = (unsigned short)q;
+            }
+            tj[M] = (unsigned short)nt;
+        }
+        // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
+        const int64_t budget = (int64_t)1 << 30;
+        int64_t nr_max = budget / (8 * (int64_t)C * nt);
+        nr_max = std::max<int64_t>(kSepRB, (nr_max / kSepRB) * kSepRB);
+        auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+            hipError_t e = b.ensure(bytes);
+            if (e != hipSuccess) return e;
+            return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        };
+        CCAL_HIP(ctx, up(ctx->sep_sb, sb.data(), sb.size() * sizeof(float)));
+        CCAL_HIP(ctx, up(ctx->sep_perm, perm.data(), perm.size() * sizeof(int)));
+        CCAL_HIP(ctx, up(ctx->sep_tab, tab.data(), tab.size() * sizeof(unsigned short)));
+        CCAL_HIP(ctx, up(ctx->sep_meta, meta.data(), meta.size() * sizeof(SepMeta)));
+        for (int64_t ra = 0; ra < R; ra += nr_max) {
+            const int nr = (int)std::min<int64_t>(nr_max, R - ra);
+            CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
+            CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
+            hipLaunchKernelGGL((separable_hist_kernel<kSepTC, kSepRB>), dim3((nr + kSepRB - 1) / kSepRB, C),
+                               dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(),
+                               cs.group_off_dev.as<int>(), ctx->sep_wr.as<f32x4>() + (size_t)ra * C,
+                               ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(),
+                               ctx->sep_tab.as<unsigned short>(), ctx->sep_meta.as<SepMeta>(),
+                               cs.scale_dev.as<double>(), C, nt, nr, ctx->partial_buf.as<double>());
+            CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
+                               0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);
+            CCAL_HIP(ctx, hipGetLastError());
+            // the host tables of this range are reused by the next launch only after this one is done
+            CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && kernel_ms) *kernel_ms += ms;
+            if (launches) ++*launches;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// Fast-path costs of grid candidates [begin, end) into device memory (*cost_local points at
+// candidate `begin`), by the dense kernels or the separable pass as the context says.
+static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_pose[6], const ccal_grid* g,
+                          int64_t begin, int64_t end, float** cost_local, double* kernel_ms, int* launches)
+{
     const int64_t n_local = end - begin;
-    if (n_local == 0) return CCAL_OK;
-    if (int rc = bind(ctx)) return rc;
-    const CloudSet& cs = ctx->sets[which];
+    *kernel_ms = 0.0;
+    *launches = 0;
+    if (ctx->search_mode == CCAL_SEARCH_SEPARABLE) {
+        const int64_t rot_count = (int64_t)g->count[3] * g->count[4] * g->count[5];
+        const int64_t t0 = begin / rot_count, t1 = (end + rot_count - 1) / rot_count;
+        // the separable pass fills whole translation rows
+        CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)((t1 - t0) * rot_count) * sizeof(float)));
+        *cost_local = ctx->cost_buf.as<float>() + (begin - t0 * rot_count);
+        return run_separable(ctx, cs, base_pose, g, t0, t1, ctx->cost_buf.as<float>(), kernel_ms, launches);
+    }
 
     // per-axis tables (host FP64, libm sin/cos)
     int tot_entries = 0;
@@ -733,14 +891,13 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, tbl.data(), tbl.size() * sizeof(double),
                                  hipMemcpyHostToDevice, ctx->stream));
     CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_local * sizeof(float)));
+    *cost_local = ctx->cost_buf.as<float>();
 
     const int64_t chunk = fast_chunk(cs);
     const int n_chunks = (int)((n_local + chunk - 1) / chunk);
-    std::vector<hipEvent_t> evs((size_t)n_chunks * 2 + 2, nullptr);
+    std::vector<hipEvent_t> evs((size_t)n_chunks * 2, nullptr);
     for (auto& e : evs) CCAL_HIP(ctx, hipEventCreate(&e));
     auto free_events = [&]() { for (auto& e : evs) if (e) (void)hipEventDestroy(e); };
-
-    CCAL_HIP(ctx, hipEventRecord(evs[2 * (size_t)n_chunks], ctx->stream));
     for (int ci = 0; ci < n_chunks; ++ci) {
         const int64_t c0 = (int64_t)ci * chunk;
         const int64_t n = std::min(chunk, n_local - c0);
@@ -751,6 +908,80 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
             return rc;
         }
     }
+    // the table upload above reads `tbl`, and the event times are wanted now
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        for (int ci = 0; ci < n_chunks; ++ci) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evs[2 * ci], evs[2 * ci + 1]) == hipSuccess) *kernel_ms += ms;
+        }
+    free_events();
+    CCAL_HIP(ctx, e);
+    *launches = n_chunks;
+    return CCAL_OK;
+}
+
+static int check_grid_call(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
+                           int64_t begin, int64_t end, const char* who)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!base_pose || !g) return fail(ctx, CCAL_ERR_ARG, std::string(who) + ": null argument");
+    if (!ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, std::string(who) + ": plane not set");
+    const int64_t total = ccal_grid_size(g);
+    if (total <= 0) return fail(ctx, CCAL_ERR_ARG, std::string(who) + ": empty grid axis");
+    if (begin < 0 || end > total || begin > end)
+        return fail(ctx, CCAL_ERR_ARG, std::string(who) + ": candidate range outside the grid");
+    return CCAL_OK;
+}
+
+extern "C" int ccal_grid_costs(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
+                               int64_t begin, int64_t end, float* cost_out)
+{
+    if (int rc = check_grid_call(ctx, which, base_pose, g, begin, end, "grid_costs")) return rc;
+    if (begin == end) return CCAL_OK;
+    if (!cost_out) return fail(ctx, CCAL_ERR_ARG, "grid_costs: null argument");
+    if (int rc = bind(ctx)) return rc;
+    float* cost_local = nullptr;
+    double kernel_ms = 0.0;
+    int launches = 0;
+    if (int rc = grid_fast_pass(ctx, ctx->sets[which], base_pose, g, begin, end, &cost_local, &kernel_ms,
+                                &launches))
+        return rc;
+    CCAL_HIP(ctx, hipMemcpyAsync(cost_out, cost_local, (size_t)(end - begin) * sizeof(float),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
+                                const ccal_grid* g, int64_t begin, int64_t end,
+                                int64_t* best_index, double* best_cost, double best_pose[6],
+                                ccal_grid_stats* stats)
+{
+    if (int rc = check_grid_call(ctx, which, base_pose, g, begin, end, "grid_search")) return rc;
+    if (!best_index || !best_cost || !best_pose)
+        return fail(ctx, CCAL_ERR_ARG, "grid_search: null argument");
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    *best_index = -1;
+    *best_cost = 1e9;  // :531
+    std::memcpy(best_pose, base_pose, 6 * sizeof(double));
+    const int64_t n_local = end - begin;
+    if (n_local == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    CCAL_HIP(ctx, hipEventCreate(&ev_begin));
+    CCAL_HIP(ctx, hipEventCreate(&ev_end));
+    auto free_events = [&]() { (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end); };
+    CCAL_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
+    float* cost_local = nullptr;
+    double kernel_ms = 0.0;
+    int launches = 0;
+    if (int rc = grid_fast_pass(ctx, cs, base_pose, g, begin, end, &cost_local, &kernel_ms, &launches)) {
+        free_events();
+        return rc;
+    }
 
     // arg-min and near-minimum band over the local cost array
     const int n_stage1 = (int)std::min<int64_t>(1024, (n_local + 255) / 256);
@@ -760,14 +991,14 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     MinRec* recs = ctx->minrec_buf.as<MinRec>();
     CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(argmin_stage1_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
-                       ctx->cost_buf.as<float>(), n_local, recs);
+                       cost_local, n_local, recs);
     hipLaunchKernelGGL(argmin_stage2_kernel, dim3(1), dim3(256), 0, ctx->stream, recs, n_stage1,
                        recs + n_stage1);
     hipLaunchKernelGGL(select_band_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
-                       ctx->cost_buf.as<float>(), n_local, recs + n_stage1, kBand,
+                       cost_local, n_local, recs + n_stage1, kBand,
                        ctx->list_buf.as<int64_t>(), kBandCap, ctx->count_buf.as<unsigned int>());
     CCAL_HIP(ctx, hipGetLastError());
-    CCAL_HIP(ctx, hipEventRecord(evs[2 * (size_t)n_chunks + 1], ctx->stream));
+    CCAL_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
 
     MinRec mn;
     unsigned int n_band = 0;
@@ -776,14 +1007,8 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     CCAL_HIP(ctx, hipMemcpyAsync(&n_band, ctx->count_buf.p, sizeof n_band, hipMemcpyDeviceToHost,
                                  ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-
-    double kernel_ms = 0.0;
-    for (int ci = 0; ci < n_chunks; ++ci) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, evs[2 * ci], evs[2 * ci + 1]) == hipSuccess) kernel_ms += ms;
-    }
     float total_ms = 0.f;
-    (void)hipEventElapsedTime(&total_ms, evs[2 * (size_t)n_chunks], evs[2 * (size_t)n_chunks + 1]);
+    (void)hipEventElapsedTime(&total_ms, ev_begin, ev_end);
     free_events();
 
     if (!(mn.cost < std::numeric_limits<float>::infinity()) || mn.index < 0)
@@ -817,7 +1042,7 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
         stats->n_rescored = n_band;
         stats->residuals = (double)n_local * (double)cs.total_pts;
         stats->kernel_ms = kernel_ms;
-        stats->kernel_launches = n_chunks;
+        stats->kernel_launches = launches;
         stats->total_ms = total_ms;
     }
     return CCAL_OK;

@@ -75,12 +75,14 @@ struct ccal_ctx {
     hipStream_t stream = nullptr;
     ccal::CloudSet sets[2];
     int fast_kernel = 0;  // CCAL_FAST_BF16X3
+    int search_mode = 0;  // CCAL_SEARCH_DENSE
     bool plane_set = false;
     float plane[4] = {0, 0, 0, 0};
     std::string err;
 
     // scratch (grow-only)
     ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
+    ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
     ccal::DevBuf mats_buf, planes_buf, psum_buf, pmax_buf, osum_buf, omax_buf, tbl_buf, dist_buf;
 };
 

@@ -840,6 +840,162 @@ __global__ __launch_bounds__(256) void select_band_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------
+// Separable grid search
+// ---------------------------------------------------------------------------
+// On a translation x rotation product grid the folded residual separates:
+//   |w.(p,1)| = |u_i(r) + b_t|,   u_i(r) = w123(r,j).(p_i - c_j) + a(r,j),   b_t = b(t,j)
+// (w123 depends on the rotation only, the constant is a rotation part plus a
+// translation part; both are taken relative to a per-cloud reference so that
+// they stay small).  For one rotation and cloud, f(b) = sum_i |u_i + b| is a
+// piecewise-linear function of the scalar b, so all translations are answered
+// from ONE pass over the points: with the b_t sorted, point i falls into bin
+// k_i = #{t : b_t < -u_i}; per bin a count and the sum of u; then with prefix
+// sums N(q), S(q) over bins <= q
+//   f(b_q) = 2 S(q) - S_total + b_q (2 N(q) - N).
+// Work per (rotation, point) is a short search and two LDS atomics instead of
+// one residual per translation.  Sums are integers (u rounded to 2^-32 m by the
+// magic-number add, accumulated with 64-bit integer atomics), so the result does
+// not depend on the order of the atomics.
+//
+// One workgroup = RB rotations x one cloud x one range of at most TC translations.
+constexpr int kSepThreads = 512;
+
+struct SepMeta {
+    float bmin;        // lowest threshold of the range
+    float inv_delta;   // buckets per metre
+};
+
+template <int TC, int RB>
+__global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
+    const f32x4* __restrict__ groups, const int* __restrict__ group_off,
+    const f32x4* __restrict__ wr,            // [rotation][cloud]: w1, w2, w3, a
+    const float* __restrict__ sb,            // [cloud][nt]: sorted translation constants
+    const int* __restrict__ perm,            // [cloud][nt]: rank -> local translation index
+    const unsigned short* __restrict__ tab,  // [cloud][2*TC + 1]: rank of each bucket's lower edge
+    const SepMeta* __restrict__ meta,        // [cloud]
+    const double* __restrict__ scale,        // [cloud]: 1 / (n_clouds * n_points)
+    int n_clouds, int nt, int nr, double* __restrict__ partial /* [cloud][nt][nr] */)
+{
+    constexpr int M = 2 * TC;
+    constexpr unsigned long long kMagicBits = 0x4138000000000000ull;   // 1.5 * 2^20
+    __shared__ unsigned int cnt[RB][TC + 1];
+    __shared__ unsigned long long sum[RB][TC + 1];
+    __shared__ float sbs[TC];
+    __shared__ unsigned short tabs[M + 1];
+    const int j = blockIdx.y;
+    const int r0 = blockIdx.x * RB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kWaves = kSepThreads / 64;
+
+    for (int i = threadIdx.x; i < nt; i += kSepThreads) sbs[i] = sb[(int64_t)j * nt + i];
+    for (int i = threadIdx.x; i <= M; i += kSepThreads) tabs[i] = tab[(int64_t)j * (M + 1) + i];
+    for (int i = threadIdx.x; i < RB * (TC + 1); i += kSepThreads) {
+        (&cnt[0][0])[i] = 0u;
+        (&sum[0][0])[i] = 0ull;
+    }
+    f32x4 w[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = r0 + rb < nr ? r0 + rb : nr - 1;   // a partial last group repeats its last rotation
+        w[rb] = wr[(int64_t)r * n_clouds + j];
+    }
+    const SepMeta mt = meta[j];
+    __syncthreads();
+
+    // points: a wave takes four 64-point groups per trip, a lane the four points of one column
+    const int g0 = group_off[j], g1 = group_off[j + 1];
+    const int col = lane & 15, gsel = lane >> 4;
+    for (int g = g0 + wave * 4 + gsel; g < g1; g += kWaves * 4) {
+        const f32x4* gp = groups + (int64_t)g * 64 + col;
+        const f32x4 x4 = gp[0], y4 = gp[16], z4 = gp[32], o4 = gp[48];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (o4[u] == 0.f) continue;                  // padding point
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                float v = __builtin_fmaf(w[rb][0], x4[u], __builtin_fmaf(w[rb][1], y4[u], w[rb][2] * z4[u])) + w[rb][3];
+                v = __builtin_fabsf(v) < 64.f ? v : (v < 0.f ? -64.f : 64.f);   // also tames NaN
+                const float key = -v;
+                // k = #{q : sbs[q] < key}: bucket table, bounded binary search, exact fix-up
+                float fb = (key - mt.bmin) * mt.inv_delta;
+                fb = fb < 0.f ? 0.f : (fb > (float)(M - 1) ? (float)(M - 1) : fb);
+                const int b = (int)fb;
+                int lo = tabs[b], hi = tabs[b + 1];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sbs[mid] < key) lo = mid + 1; else hi = mid;
+                }
+                int k = lo;
+                while (k < nt && sbs[k] < key) ++k;
+                while (k > 0 && !(sbs[k - 1] < key)) --k;
+                const double dv = (double)v + 1572864.0;   // 1.5 * 2^20: low bits = v * 2^32, rounded
+                atomicAdd(&cnt[rb][k], 1u);
+                atomicAdd(&sum[rb][k], (unsigned long long)__double_as_longlong(dv));
+            }
+        }
+    }
+    __syncthreads();
+
+    // inclusive prefix sums over the bins, one wave per rotation
+    for (int rb = wave; rb < RB; rb += kWaves) {
+        unsigned long long cn = 0;
+        long long cs = 0;
+        for (int base = 0; base <= nt; base += 64) {
+            const int k = base + lane;
+            unsigned long long c = 0;
+            long long sv = 0;
+            if (k <= nt) {
+                c = cnt[rb][k];
+                sv = (long long)(sum[rb][k] - c * kMagicBits);
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long c2 = __shfl_up(c, off, 64);
+                const long long s2 = __shfl_up(sv, off, 64);
+                if (lane >= off) { c += c2; sv += s2; }
+            }
+            c += cn;
+            sv += cs;
+            if (k <= nt) {
+                cnt[rb][k] = (unsigned int)c;
+                sum[rb][k] = (unsigned long long)sv;
+            }
+            cn = __shfl(c, 63, 64);
+            cs = __shfl(sv, 63, 64);
+        }
+    }
+    __syncthreads();
+
+    const double sc = scale[j];
+    for (int q = threadIdx.x; q < nt; q += kSepThreads) {
+        const double bq = (double)sbs[q];
+        const int tl = perm[(int64_t)j * nt + q];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (r0 + rb >= nr) break;
+            const double n_le = (double)cnt[rb][q], n_all = (double)cnt[rb][nt];
+            const double s_le = (double)(long long)sum[rb][q], s_all = (double)(long long)sum[rb][nt];
+            const double f = (2.0 * s_le - s_all) * (1.0 / 4294967296.0) + bq * (2.0 * n_le - n_all);
+            partial[((int64_t)j * nt + tl) * nr + (r0 + rb)] = f * sc;
+        }
+    }
+}
+
+// cost[(t_off + tl) * row + r_off + rl] = sum over clouds (in cloud order) of partial[cloud][tl][rl]
+__global__ __launch_bounds__(256) void separable_reduce_kernel(const double* __restrict__ partial,
+                                                                int n_clouds, int nt, int nr,
+                                                                float* __restrict__ cost, int64_t row,
+                                                                int64_t t_off, int64_t r_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)nt * nr) return;
+    double s = 0.0;
+    for (int j = 0; j < n_clouds; ++j) s += partial[(int64_t)j * nt * nr + i];
+    const int64_t tl = i / nr, rl = i % nr;
+    cost[(t_off + tl) * row + r_off + rl] = (float)s;
+}
+
+// ---------------------------------------------------------------------------
 // Exact path
 // ---------------------------------------------------------------------------
 // A block covers a contiguous run of points of one cloud.

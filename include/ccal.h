@@ -131,6 +131,18 @@ int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* pose
 enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1, CCAL_FAST_BF16X3_WIDE = 2 };
 int ccal_set_fast_kernel(ccal_ctx* ctx, int kind);
 
+/* How ccal_grid_search scores the grid on the fast path (no counterpart in the reference;
+ * the result is the same either way, because the near-minimum candidates are re-scored
+ * with ccal_eval arithmetic):
+ *   CCAL_SEARCH_DENSE (default)  every (candidate, point) residual is evaluated on the
+ *                                matrix cores;
+ *   CCAL_SEARCH_SEPARABLE        the grid is a translation x rotation product, and for a
+ *                                fixed rotation the cost is a piecewise-linear function of
+ *                                one scalar per translation: one histogram pass over the
+ *                                points per rotation answers all its translations. */
+enum { CCAL_SEARCH_DENSE = 0, CCAL_SEARCH_SEPARABLE = 1 };
+int ccal_set_search_mode(ccal_ctx* ctx, int mode);
+
 /* Candidate grid of discreteCombinatorialOptimization (:526-558), generalised:
  * axis k perturbs pose[k]; axes 0..2 in millimetres, 3..5 in degrees
  * (rad = deg*3.141592/180 as helpers.hpp:275-278); value_i = min + i*step;
@@ -168,6 +180,13 @@ int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
                      const ccal_grid* g, int64_t begin, int64_t end,
                      int64_t* best_index, double* best_cost, double best_pose[6],
                      ccal_grid_stats* stats);
+
+/* Fast-path cost of every candidate of [begin,end) (cost_out[i] = candidate begin + i): the
+ * landscape ccal_grid_search minimises before its exact re-score, computed the way the
+ * current search mode computes it.  The reference keeps only the running minimum of
+ * :541-547; this exposes the whole sweep for inspection and tests. */
+int ccal_grid_costs(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
+                    int64_t begin, int64_t end, float* cost_out);
 
 /* Lexicographic (cost, index) minimum over n shard results; entries with
  * index < 0 (empty shards) are skipped.  Returns the winning slot or -1. */

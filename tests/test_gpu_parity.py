@@ -206,6 +206,45 @@ def test_fast_eval_large_batch_linear_properties(gpu_opt):
     np.testing.assert_allclose(fast[:64], exact, rtol=FAST_RTOL)
 
 
+def test_separable_search_equals_dense(gpu_opt, oracle):
+    """The histogram pass per rotation gives the dense kernel's costs (to the fast tolerance) for every
+    candidate, on ragged clouds, for ranges that cut translation rows and for more translations than one
+    launch holds, and the search result is the oracle's."""
+    import cameracalibration_amd as cc
+    s = make_scene(5, 7000, seed=77, ragged=True)
+    upload(gpu_opt, s)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    try:
+        for counts in ([3, 4, 5, 4, 3, 5], [11, 11, 11, 2, 2, 2]):       # 60 and 1331 translations
+            g = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / max(c - 1, 1) for c in counts[:3]] +
+                             [10.0 / max(c - 1, 1) for c in counts[3:]], counts)
+            rot = counts[3] * counts[4] * counts[5]
+            begin, end = rot + 7, g.size - rot - 3                       # cuts the first and last rows used
+            gpu_opt.set_search_mode(0)
+            dense = gpu_opt.grid_costs(s.pose_init, g, begin, end)
+            want = gpu_opt.grid_search(s.pose_init, g, begin, end)
+            gpu_opt.set_search_mode(1)
+            sep = gpu_opt.grid_costs(s.pose_init, g, begin, end)
+            got = gpu_opt.grid_search(s.pose_init, g, begin, end)
+            np.testing.assert_allclose(sep, dense, rtol=FAST_RTOL)
+            assert (got[0], got[1]) == (want[0], want[1])
+            np.testing.assert_array_equal(got[2], want[2])
+            full = gpu_opt.grid_costs(s.pose_init, g)
+            np.testing.assert_array_equal(full[begin:end], sep)         # rows are independent of the range
+        # a few candidates against the oracle's own cost
+        g = cc.Grid.make([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6)
+        sep = gpu_opt.grid_costs(s.pose_init, g)
+        og = oracle.make_grid([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6)
+        for idx in (0, 1234, 7777, g.size - 1):
+            pose = oracle.grid_pose(og, s.pose_init, idx)
+            assert abs(sep[idx] - o.get_error(pose, s.plane)) <= FAST_RTOL * sep[idx]
+        idx, cost, _, _ = gpu_opt.grid_search(s.pose_init, g)
+        oi, oc, _, _ = o.grid_search(s.plane, s.pose_init, og)
+        assert (idx, cost) == (oi, oc)
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
 def test_grid_search_matches_oracle_small(gpu_opt, oracle, synthetic_golden):
     for rec in synthetic_golden.values():
         s = make_scene(rec["n_clouds"], rec["n_points"], seed=rec["seed"], ragged=rec["ragged"])
