@@ -769,7 +769,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     constexpr int M = 2 * kSepTC;
     std::vector<float> sb;
     std::vector<int> perm;
-    std::vector<unsigned short> tab;
+    std::vector<unsigned> tab;
     std::vector<SepMeta> meta(C);
     std::vector<std::pair<float, int>> order;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -780,7 +780,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
         const int nt = (int)std::min<int64_t>(kSepTC, t1 - ta);
         sb.assign((size_t)C * nt, 0.f);
         perm.assign((size_t)C * nt, 0);
-        tab.assign((size_t)C * (M + 1), 0);
+        tab.assign((size_t)C * M, 0u);
         for (int j = 0; j < C; ++j) {
             order.resize(nt);
             for (int tl = 0; tl < nt; ++tl) {
@@ -797,14 +797,14 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             const double delta = bmax > bmin ? ((double)bmax - (double)bmin) / M : 1.0;
             meta[j].bmin = bmin;
             meta[j].inv_delta = (float)(1.0 / delta);
-            unsigned short* tj = tab.data() + (size_t)j * (M + 1);
+            // rank range [lo, hi] of every bucket: lo = thresholds in lower buckets, hi = lo + its own
+            unsigned* tj = tab.data() + (size_t)j * M;
             int q = 0;
-            for (int m = 0; m <= M; ++m) {
-                const double edge = (double)bmin + m * delta;
-                while (q < nt && (double)order[q].first < edge) ++q;
-                tj[m] = (unsigned short)q;
+            for (int m = 0; m < M; ++m) {
+                const int lo = q;
+                while (q < nt && separable_bucket(order[q].first, meta[j], M) <= m) ++q;
+                tj[m] = (unsigned)lo | ((unsigned)q << 16);
             }
-            tj[M] = (unsigned short)nt;
         }
         // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
         const int64_t budget = (int64_t)1 << 30;
@@ -817,7 +817,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
         };
         CCAL_HIP(ctx, up(ctx->sep_sb, sb.data(), sb.size() * sizeof(float)));
         CCAL_HIP(ctx, up(ctx->sep_perm, perm.data(), perm.size() * sizeof(int)));
-        CCAL_HIP(ctx, up(ctx->sep_tab, tab.data(), tab.size() * sizeof(unsigned short)));
+        CCAL_HIP(ctx, up(ctx->sep_tab, tab.data(), tab.size() * sizeof(unsigned)));
         CCAL_HIP(ctx, up(ctx->sep_meta, meta.data(), meta.size() * sizeof(SepMeta)));
         for (int64_t ra = 0; ra < R; ra += nr_max) {
             const int nr = (int)std::min<int64_t>(nr_max, R - ra);
@@ -827,7 +827,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
                                dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(),
                                cs.group_off_dev.as<int>(), ctx->sep_wr.as<f32x4>() + (size_t)ra * C,
                                ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(),
-                               ctx->sep_tab.as<unsigned short>(), ctx->sep_meta.as<SepMeta>(),
+                               ctx->sep_tab.as<unsigned>(), ctx->sep_meta.as<SepMeta>(),
                                cs.scale_dev.as<double>(), C, nt, nr, ctx->partial_buf.as<double>());
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),

@@ -865,13 +865,22 @@ struct SepMeta {
     float inv_delta;   // buckets per metre
 };
 
+// Bucket of a key among n_buckets equal slices of [bmin, bmax]; monotone in the key.  Host
+// (table construction) and device (lookup) evaluate this same float expression.
+__host__ __device__ inline int separable_bucket(float key, const SepMeta& mt, int n_buckets)
+{
+    float fb = (key - mt.bmin) * mt.inv_delta;
+    fb = fb < 0.f ? 0.f : (fb > (float)(n_buckets - 1) ? (float)(n_buckets - 1) : fb);
+    return (int)fb;
+}
+
 template <int TC, int RB>
 __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off,
     const f32x4* __restrict__ wr,            // [rotation][cloud]: w1, w2, w3, a
     const float* __restrict__ sb,            // [cloud][nt]: sorted translation constants
     const int* __restrict__ perm,            // [cloud][nt]: rank -> local translation index
-    const unsigned short* __restrict__ tab,  // [cloud][2*TC + 1]: rank of each bucket's lower edge
+    const unsigned* __restrict__ tab,        // [cloud][2*TC]: rank range of each bucket, lo | hi << 16
     const SepMeta* __restrict__ meta,        // [cloud]
     const double* __restrict__ scale,        // [cloud]: 1 / (n_clouds * n_points)
     int n_clouds, int nt, int nr, double* __restrict__ partial /* [cloud][nt][nr] */)
@@ -881,14 +890,14 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     __shared__ unsigned int cnt[RB][TC + 1];
     __shared__ unsigned long long sum[RB][TC + 1];
     __shared__ float sbs[TC];
-    __shared__ unsigned short tabs[M + 1];
+    __shared__ unsigned tabs[M];
     const int j = blockIdx.y;
     const int r0 = blockIdx.x * RB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kWaves = kSepThreads / 64;
 
     for (int i = threadIdx.x; i < nt; i += kSepThreads) sbs[i] = sb[(int64_t)j * nt + i];
-    for (int i = threadIdx.x; i <= M; i += kSepThreads) tabs[i] = tab[(int64_t)j * (M + 1) + i];
+    for (int i = threadIdx.x; i < M; i += kSepThreads) tabs[i] = tab[(int64_t)j * M + i];
     for (int i = threadIdx.x; i < RB * (TC + 1); i += kSepThreads) {
         (&cnt[0][0])[i] = 0u;
         (&sum[0][0])[i] = 0ull;
@@ -916,18 +925,15 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
                 float v = __builtin_fmaf(w[rb][0], x4[u], __builtin_fmaf(w[rb][1], y4[u], w[rb][2] * z4[u])) + w[rb][3];
                 v = __builtin_fabsf(v) < 64.f ? v : (v < 0.f ? -64.f : 64.f);   // also tames NaN
                 const float key = -v;
-                // k = #{q : sbs[q] < key}: bucket table, bounded binary search, exact fix-up
-                float fb = (key - mt.bmin) * mt.inv_delta;
-                fb = fb < 0.f ? 0.f : (fb > (float)(M - 1) ? (float)(M - 1) : fb);
-                const int b = (int)fb;
-                int lo = tabs[b], hi = tabs[b + 1];
+                // k = #{q : sbs[q] < key}: the bucket function is monotone and the table was built
+                // with this very expression, so k lies in the bucket's rank range [lo, hi]
+                const unsigned e = tabs[separable_bucket(key, mt, M)];
+                int lo = (int)(e & 0xffffu), hi = (int)(e >> 16);
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (sbs[mid] < key) lo = mid + 1; else hi = mid;
                 }
-                int k = lo;
-                while (k < nt && sbs[k] < key) ++k;
-                while (k > 0 && !(sbs[k - 1] < key)) --k;
+                const int k = lo;
                 const double dv = (double)v + 1572864.0;   // 1.5 * 2^20: low bits = v * 2^32, rounded
                 atomicAdd(&cnt[rb][k], 1u);
                 atomicAdd(&sum[rb][k], (unsigned long long)__double_as_longlong(dv));

@@ -8,7 +8,8 @@ s = make_scene(nc, npts)
 opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
 g = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (axis - 1)] * 3 + [10.0 / (axis - 1)] * 3, [axis] * 6)
-for mode in (1, 0):
+modes = [int(m) for m in sys.argv[4].split(',')] if len(sys.argv) > 4 else [1, 0]
+for mode in modes:
     opt.set_search_mode(mode)
     for rep in range(3):
         t = time.time(); idx, cost, pose, st = opt.grid_search(s.pose_init, g); dt = time.time() - t
