@@ -31,6 +31,7 @@ struct Inputs {
     double pose_init[6];
     ccal_grid grid;
     int n_gpus = 1;
+    int search_mode = CCAL_SEARCH_SEPARABLE;   // same result as the dense sweep, O(rotations x points) work
     ccal_gd_opts gd;
     std::string config_out;   // optional <output><config>: refined config written here
 };
@@ -108,6 +109,12 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
         in.grid.count[k] = (int)num(*root, grp + ".count", in.grid.count[k]);
     }
     in.n_gpus = (int)num(*root, "data.device.gpus", 1);
+    {
+        const std::string mode = trim(root->get("data.search.mode", ""));
+        if (mode == "dense") in.search_mode = CCAL_SEARCH_DENSE;
+        else if (mode == "separable" || mode.empty()) in.search_mode = CCAL_SEARCH_SEPARABLE;
+        else throw std::runtime_error("config: <search><mode> must be dense or separable");
+    }
     ccal_gd_default_opts(&in.gd);
     in.gd.max_iterations = (int)num(*root, "data.search.gd_max_iterations", in.gd.max_iterations);
     in.config_out = trim(root->get("data.output.config", ""));
@@ -193,6 +200,7 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         float plane[4];
         Check{ctx}(ccal_fit_plane_lsq(ctx, CCAL_RAW, in.pose_init, plane), "fit_plane_lsq");
         for (auto* c : ctxs) Check{c}(ccal_set_plane(c, plane), "set_plane");
+        for (auto* c : ctxs) Check{c}(ccal_set_search_mode(c, in.search_mode), "set_search_mode");
         if (chatty) {
             std::cout << "Plane Equation 2: " << std::endl;
             for (int i = 0; i < 4; ++i) std::cout << plane[i] << " ";
