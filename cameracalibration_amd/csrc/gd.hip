@@ -15,13 +15,19 @@
 //                f(x-alpha g) <= f - c1 alpha g.g  and  g.g(x-alpha g) <= c2 g.g
 //       step   = momentum*step + (1-momentum)*alpha*g
 //
-// Every stencil (the point itself and +-eps/2 along each axis) is evaluated by
-// batched calls into the exact objective; several independent descents advance
-// in lock step and share those calls.  The backtracking trials of one line
-// search are known in advance (alpha = 0.8^k), so a run of them is evaluated
-// speculatively in one pass and then consumed in order with exactly the
-// sequential accept/continue logic; values past the accepted trial are dropped
-// (and not counted), so iterates and evaluation counts equal the one-by-one run.
+// Objective values come from batched calls into the exact objective; several
+// independent descents advance in lock step and share those calls.  Two facts
+// keep the batches small without changing a single iterate:
+//   * the backtracking trials of one line search are known in advance
+//     (alpha = 0.8^k), so the centres of a run of them are evaluated in one pass
+//     and consumed in order with the sequential accept/continue logic;
+//   * a trial that fails the Armijo test is rejected whatever its gradient, so
+//     the 2*dim finite-difference points of a trial are evaluated only once its
+//     centre has passed Armijo; the main stencil of the next iteration rides
+//     along with them, computed as if the curvature test passes (it is dropped
+//     if it does not).
+// Values past the accepted trial are dropped.  The evaluation count reported is
+// that of the sequential algorithm (1 + 2*dim per trial it visits).
 #include "ccal_internal.hpp"
 
 #include <cfloat>
@@ -42,24 +48,27 @@ struct Machine {
     int64_t n_evals = 0;
     int64_t n_requested = 0;   // evaluations asked of the device, dropped speculation included
     int64_t n_requests = 0;
+    int64_t n_trials = 0, n_armijo_fail = 0, n_wolfe_only_fail = 0;
     // line search
     double alpha = 0.0, gg = 0.0, xn[10];
     int ls_it = 0;
-    enum Phase { MAIN, TRIAL, DONE } phase = DONE;
+    // TRIAL_F: objective values at the centres of the next trials (Armijo needs nothing else);
+    // TRIAL_G: the +-eps/2 points of the one trial that passed Armijo (curvature test)
+    enum Phase { MAIN, TRIAL_F, TRIAL_G, DONE } phase = DONE;
     // speculation: trials per request (first request of a line search / later ones)
     int last_trials = 3;
     bool first_request = true;
-    static constexpr int kMaxSpeculated = 48;
+    static constexpr int kMaxSpeculated = 64;
+    int64_t n_main_hits = 0;
 
     int stencil() const { return 1 + 2 * D; }
 
-    // trials the next request evaluates (>= 1 in TRIAL phase)
+    // trials whose centres the next TRIAL_F request evaluates (>= 1)
     int planned_trials() const
     {
-        if (phase != TRIAL) return 1;
-        // a short request costs about as much as six wasted trials, and trial counts of
-        // consecutive iterations differ by a few: one spare trial measured best
-        int want = first_request ? last_trials + 1 : 4;
+        // centres are cheap (one pose each) and a short request costs about as much as a
+        // dozen of them, so speculate a few trials past the previous line search's count
+        int want = first_request ? last_trials + 4 : 8;
         if (want > kMaxSpeculated) want = kMaxSpeculated;
         if (want < 1) want = 1;
         int n = 1;
@@ -73,7 +82,21 @@ struct Machine {
         return n;
     }
 
-    int request_points() const { return stencil() * planned_trials(); }
+    // the main stencil of the next iteration, should the trial at xn be accepted
+    void next_main_point(double* xs) const
+    {
+        for (int k = 0; k < D; ++k) {
+            const double st = o.momentum * step[k] + (1 - o.momentum) * alpha * grad[k];
+            xs[k] = x[k] - st;
+        }
+    }
+
+    int request_points() const
+    {
+        if (phase == MAIN) return stencil();
+        if (phase == TRIAL_G) return 2 * D + stencil();
+        return planned_trials();
+    }
 
     bool keep_going() const
     {
@@ -103,11 +126,11 @@ struct Machine {
         phase = MAIN;
     }
 
-    void emit_stencil(const double* c, double* out) const
+    // the 2*D points c +- eps/2 along each axis (plus first)
+    void emit_axis_points(const double* c, double* out) const
     {
-        std::memcpy(out, c, sizeof(double) * D);
         for (int i = 0; i < 2 * D; ++i) {
-            double* p = out + (size_t)(1 + i) * D;
+            double* p = out + (size_t)i * D;
             std::memcpy(p, c, sizeof(double) * D);
             if (i % 2 == 0) p[i / 2] += o.fd_eps / 2;
             else            p[i / 2] -= o.fd_eps / 2;
@@ -117,13 +140,27 @@ struct Machine {
     // writes request_points() points of D doubles each
     void emit(double* out) const
     {
-        if (phase == MAIN) { emit_stencil(x, out); return; }
+        if (phase == MAIN) {
+            std::memcpy(out, x, sizeof(double) * D);
+            emit_axis_points(x, out + D);
+            return;
+        }
+        if (phase == TRIAL_G) {
+            // a trial that passed Armijo has (so far always) passed the curvature test too, so the
+            // next iteration's main stencil rides along with its gradient points
+            double xs[10];
+            emit_axis_points(xn, out);
+            next_main_point(xs);
+            std::memcpy(out + (size_t)2 * D * D, xs, sizeof(double) * D);
+            emit_axis_points(xs, out + (size_t)(2 * D + 1) * D);
+            return;
+        }
         const int n = planned_trials();
         double a = alpha, c[10];
         for (int t = 0; t < n; ++t) {
             if (t > 0) a = o.wolfe_decrease * a;   // same recurrence as next_trial()
             for (int k = 0; k < D; ++k) c[k] = x[k] - a * grad[k];
-            emit_stencil(c, out + (size_t)t * stencil() * D);
+            std::memcpy(out + (size_t)t * D, c, sizeof(double) * D);
         }
     }
 
@@ -144,7 +181,7 @@ struct Machine {
     {
         alpha = o.wolfe_decrease * alpha;
         for (int k = 0; k < D; ++k) xn[k] = x[k] - alpha * grad[k];
-        phase = TRIAL;
+        phase = TRIAL_F;
     }
 
     void finish_iteration()
@@ -158,41 +195,74 @@ struct Machine {
         begin_iteration();
     }
 
+    // f: values at emit_axis_points order
     void gradient_of(const double* f, double* g) const
     {
-        for (int k = 0; k < D; ++k) g[k] = (f[1 + 2 * k] - f[2 + 2 * k]) / o.fd_eps;
+        for (int k = 0; k < D; ++k) g[k] = (f[2 * k] - f[2 * k + 1]) / o.fd_eps;
     }
 
-    // f holds request_points() objective values in emit() order
+    // The trial at xn passed Armijo and g is the gradient there: curvature test, then either the
+    // iteration ends or the next trial is set up (phase TRIAL_F).  Returns true if the iteration ended.
+    bool conclude_trial(const double* g)
+    {
+        const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
+        ++ls_it;
+        ++n_trials;
+        n_evals += stencil();
+        if (!wolfe) ++n_wolfe_only_fail;
+        if (!wolfe && trial_allowed()) { next_trial(); return false; }
+        finish_iteration();
+        return true;
+    }
+
+    // f: objective at x and at its 2*D axis points
+    void feed_main(const double* f)
+    {
+        double g[10];
+        n_evals += stencil();
+        gradient_of(f + 1, g);
+        fval = f[0];
+        std::memcpy(grad, g, sizeof(double) * D);
+        gg = dot(grad, grad, D);
+        grad_len = std::sqrt(gg);
+        alpha = o.wolfe_max_step / o.wolfe_decrease;
+        ls_it = 0;
+        first_request = true;
+        if (trial_allowed()) next_trial();
+        else finish_iteration();
+    }
+
+    // f holds request_points() objective values in emit() order.  Every trial the sequential
+    // algorithm evaluates (centre and gradient, 1 + 2*D values) is counted in n_evals whether or
+    // not its gradient was needed here: a trial that fails Armijo is rejected whatever its gradient.
     void feed(const double* f)
     {
         double g[10];
         n_requested += request_points();
         ++n_requests;
         if (phase == MAIN) {
-            n_evals += stencil();
+            feed_main(f);
+        } else if (phase == TRIAL_G) {
+            double xs[10];
+            next_main_point(xs);
             gradient_of(f, g);
-            fval = f[0];
-            std::memcpy(grad, g, sizeof(double) * D);
-            gg = dot(grad, grad, D);
-            grad_len = std::sqrt(gg);
-            alpha = o.wolfe_max_step / o.wolfe_decrease;
-            ls_it = 0;
-            first_request = true;
-            if (trial_allowed()) next_trial();
-            else finish_iteration();
-        } else if (phase == TRIAL) {
+            first_request = false;
+            if (conclude_trial(g) && phase == MAIN && std::memcmp(xs, x, sizeof(double) * D) == 0) {
+                ++n_main_hits;
+                feed_main(f + 2 * D);   // the stencil that rode along is the one now due
+            }
+        } else if (phase == TRIAL_F) {
             const int n = planned_trials();
             first_request = false;
             for (int t = 0; t < n; ++t) {
-                const double* ft = f + (size_t)t * stencil();
-                n_evals += stencil();
-                gradient_of(ft, g);
-                const bool armijo = ft[0] <= fval - o.wolfe_c1 * alpha * gg;
-                const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
+                const bool armijo = f[t] <= fval - o.wolfe_c1 * alpha * gg;
+                if (armijo) { phase = TRIAL_G; return; }   // xn is this trial's point
                 ++ls_it;
-                if (!(armijo && wolfe) && trial_allowed()) next_trial();
-                else { finish_iteration(); return; }
+                ++n_trials;
+                ++n_armijo_fail;
+                n_evals += stencil();
+                if (!trial_allowed()) { finish_iteration(); return; }
+                next_trial();
             }
         }
     }
@@ -288,8 +358,12 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
     }
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
-            std::fprintf(stderr, "gd[%d]: %lld evaluations used, %lld requested in %lld requests\n", s,
-                         (long long)ms[s].n_evals, (long long)ms[s].n_requested, (long long)ms[s].n_requests);
+            std::fprintf(stderr, "gd[%d]: %lld evaluations of the sequential algorithm, %lld evaluated in %lld requests; %lld trials, "
+                         "%lld failed Armijo, %lld passed Armijo but failed the curvature test; %lld main "
+                         "stencils rode along with a gradient\n", s,
+                         (long long)ms[s].n_evals, (long long)ms[s].n_requested, (long long)ms[s].n_requests,
+                         (long long)ms[s].n_trials, (long long)ms[s].n_armijo_fail, (long long)ms[s].n_wolfe_only_fail,
+                         (long long)ms[s].n_main_hits);
     for (int s = 0; s < n_starts; ++s) ms[s].result(&results[s]);
     return CCAL_OK;
 }
