@@ -1295,6 +1295,8 @@ __device__ inline void chain_fold_run(const double d[kChainRun], double scale, u
     inc0 = sum;
     inc1 = sum;
     if (__builtin_expect(tie, 0)) {
+        // keep this rare path's arithmetic out of the common one (no shared subexpressions)
+        asm volatile("" : "+v"(scale));
         inc0 = 0; inc1 = 0;
 #pragma unroll
         for (int t = 0; t < kChainRun; ++t) {
@@ -1319,9 +1321,11 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
     static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "W must be a power of two");
     constexpr int kPass = kChainSeg * W;
     constexpr unsigned long long kTwo53 = 1ull << 53;
+    constexpr unsigned long long kMantissa = (1ull << 52) - 1;
     const double two52 = 4503599627370496.0;
     __shared__ unsigned long long sh_inc[W][2];
     __shared__ int sh_ok[W];
+    __shared__ int sh_tie[W];
     __shared__ unsigned long long sh_S;
     __shared__ int sh_adv;
     __shared__ double sh_s;
@@ -1382,7 +1386,10 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
             }
             // scale = 1/u = 2^(52 - e): exponent field 1023 + 52 - (ebiased - 1023)
             const double scale = __longlong_as_double((long long)((unsigned long long)(2098 - ebiased) << 52));
-            const double unit = __longlong_as_double((long long)((unsigned long long)(ebiased - 52) << 52));
+            // an integer count of units in [2^52, 2^53) back to a double of this binade: exact
+            auto from_units = [ebiased](unsigned long long n) {
+                return __longlong_as_double((long long)((n & kMantissa) | ((unsigned long long)ebiased << 52)));
+            };
             // this lane's map; consumed lanes are the identity
             unsigned long long inc0 = 0, inc1 = 0;
             bool ok = true, tie = false;
@@ -1392,32 +1399,38 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
                     ok = finite && run_max * scale < two52;
                     if (ok) chain_fold_run(d, scale, inc0, inc1, tie);
                 }
-                unsigned long long t0 = inc0, t1 = inc1;
-                if (!__any(tie ? 1 : 0)) {
-                    // no ties in the segment: both parities add the plain sum
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) t0 += __shfl_xor(t0, off, 64);
-                    t1 = t0;
+                const bool wave_tie = __any(tie ? 1 : 0);
+                if (!wave_tie) {
+                    // no ties in the segment: both parities add the plain sum of the lane totals,
+                    // formed by the LDS adder (a wave's LDS operations execute in order)
+                    if (lane == 0) sh_inc[wave][0] = 0ull;
+                    atomicAdd(&sh_inc[wave][0], inc0);
                 } else {
+                    unsigned long long t0 = inc0, t1 = inc1;
                     chain_compose_wave(t0, t1);
+                    if (lane == 0) { sh_inc[wave][0] = t0; sh_inc[wave][1] = t1; }
                 }
                 const bool all_ok = __all(ok ? 1 : 0);
                 if (lane == 0) {
-                    // totals of 2^53 or more are rejected whatever their value: clamp so that
-                    // the composition over segments cannot wrap
-                    sh_inc[wave][0] = t0 < (kTwo53 << 1) ? t0 : (kTwo53 << 1);
-                    sh_inc[wave][1] = t1 < (kTwo53 << 1) ? t1 : (kTwo53 << 1);
                     sh_ok[wave] = all_ok ? 1 : 0;
+                    sh_tie[wave] = wave_tie ? 1 : 0;
                 }
             }
             __syncthreads();
             if (wave == 0) {
                 const int first_seg = consumed / kChainSeg;
-                const unsigned long long S = (unsigned long long)(s * scale);   // exact integer in [2^52, 2^53)
+                // S = s / unit, an integer in [2^52, 2^53): the significand of s with its hidden bit
+                const unsigned long long S = (sbits & kMantissa) | (1ull << 52);
                 unsigned long long a0 = 0, a1 = 0;
                 bool seg_ok = true;
                 if (lane >= first_seg && lane < nseg) {
-                    a0 = sh_inc[lane][0]; a1 = sh_inc[lane][1]; seg_ok = sh_ok[lane] != 0;
+                    a0 = sh_inc[lane][0];
+                    a1 = sh_tie[lane] ? sh_inc[lane][1] : a0;
+                    // totals of 2^53 or more are rejected whatever their value: clamp so that
+                    // the composition over segments cannot wrap
+                    a0 = a0 < (kTwo53 << 1) ? a0 : (kTwo53 << 1);
+                    a1 = a1 < (kTwo53 << 1) ? a1 : (kTwo53 << 1);
+                    seg_ok = sh_ok[lane] != 0;
                 }
                 chain_scan<W>(a0, a1, lane);
                 const unsigned long long tot = (S & 1ull) ? a1 : a0;
@@ -1434,7 +1447,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
             const int adv = sh_adv;
             const unsigned long long Sx = sh_S;
             if (adv >= nseg) {
-                s = (double)Sx * unit;                                       // exact
+                s = from_units(Sx);
                 break;
             }
             if (wave == adv) {
@@ -1446,7 +1459,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
                 const int L = mask ? __builtin_ctzll(mask) : 63;             // mask is never empty here
                 const unsigned long long before = __shfl(tot, L > 0 ? L - 1 : 0, 64);
                 if (lane == L) {
-                    double sv = (double)(L > 0 ? Sx + before : Sx) * unit;   // exact
+                    double sv = from_units(L > 0 ? Sx + before : Sx);
 #pragma unroll
                     for (int t = 0; t < kChainRun; ++t) sv += d[t];
                     sh_s = sv;
