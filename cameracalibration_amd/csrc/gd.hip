@@ -60,6 +60,7 @@ struct Machine {
     bool first_request = true;
     static constexpr int kMaxSpeculated = 64;
     int64_t n_main_hits = 0;
+    int chains_per_pose = 0, round_chains = 0;   // set for a single descent: clouds, compute units
 
     int stencil() const { return 1 + 2 * D; }
 
@@ -69,6 +70,13 @@ struct Machine {
         // centres are cheap (one pose each) and a short request costs about as much as a
         // dozen of them, so speculate a few trials past the previous line search's count
         int want = first_request ? last_trials + 4 : 8;
+        // the device works through one chain per (pose, cloud) in rounds of `round_chains`
+        // workgroups: more centres are free up to the end of the round the request needs anyway
+        if (round_chains > 0 && chains_per_pose > 0) {
+            const int rounds = (want * chains_per_pose + round_chains - 1) / round_chains;
+            const int fill = rounds * round_chains / chains_per_pose;
+            if (fill > want) want = fill;
+        }
         if (want > kMaxSpeculated) want = kMaxSpeculated;
         if (want < 1) want = 1;
         int n = 1;
@@ -321,6 +329,10 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
 
     std::vector<Machine> ms(n_starts);
     for (int s = 0; s < n_starts; ++s) ms[s].start(dim, x0 + (size_t)s * dim, o);
+    if (n_starts == 1) {
+        ms[0].chains_per_pose = ctx->sets[which].n_clouds;
+        ms[0].round_chains = ctx->n_cu;
+    }
 
     std::vector<double> pts, poses, planes, f;
     std::vector<int> active;
