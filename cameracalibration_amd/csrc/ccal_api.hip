@@ -695,8 +695,18 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
 // ---------------------------------------------------------------------------
 // separable search: all translations of a rotation from one pass over the points
 // ---------------------------------------------------------------------------
-constexpr int kSepTC = 1024;  // translations per launch (histogram bins in LDS)
-constexpr int kSepRB = 4;     // rotations per workgroup
+// Translations per launch (histogram bins in LDS) x rotations per workgroup: 1024 x 4 when one
+// launch holds all translations (57 KB of LDS); 2048 x 2 for longer lists, which halves the
+// number of passes over the points (73 KB).
+template <int TC, int RB>
+static void launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr)
+{
+    hipLaunchKernelGGL((separable_hist_kernel<TC, RB>), dim3((nr + RB - 1) / RB, cs.n_clouds),
+                       dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+                       wr, ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(), ctx->sep_tab.as<unsigned>(),
+                       ctx->sep_meta.as<SepMeta>(), cs.scale_dev.as<double>(), cs.n_clouds, nt, nr,
+                       ctx->partial_buf.as<double>());
+}
 
 // Fast-path costs of translations [t0, t1) x all R rotations of the grid into
 // cost[(t - t0) * R + r] (device).  kernel_ms accumulates the histogram kernel's time.
@@ -766,7 +776,9 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->sep_wr.p, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice,
                                  ctx->stream));
 
-    constexpr int M = 2 * kSepTC;
+    const bool long_list = t1 - t0 > 1024;
+    const int tc = long_list ? 2048 : 1024, rb = long_list ? 2 : 4;
+    const int M = 2 * tc;
     std::vector<float> sb;
     std::vector<int> perm;
     std::vector<unsigned> tab;
@@ -776,8 +788,8 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     CCAL_HIP(ctx, hipEventCreate(&e0));
     CCAL_HIP(ctx, hipEventCreate(&e1));
     int rc = CCAL_OK;
-    for (int64_t ta = t0; ta < t1 && rc == CCAL_OK; ta += kSepTC) {
-        const int nt = (int)std::min<int64_t>(kSepTC, t1 - ta);
+    for (int64_t ta = t0; ta < t1 && rc == CCAL_OK; ta += tc) {
+        const int nt = (int)std::min<int64_t>(tc, t1 - ta);
         sb.assign((size_t)C * nt, 0.f);
         perm.assign((size_t)C * nt, 0);
         tab.assign((size_t)C * M, 0u);
@@ -809,7 +821,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
         // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
         const int64_t budget = (int64_t)1 << 30;
         int64_t nr_max = budget / (8 * (int64_t)C * nt);
-        nr_max = std::max<int64_t>(kSepRB, (nr_max / kSepRB) * kSepRB);
+        nr_max = std::max<int64_t>(rb, (nr_max / rb) * rb);
         auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
             hipError_t e = b.ensure(bytes);
             if (e != hipSuccess) return e;
@@ -823,12 +835,8 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             const int nr = (int)std::min<int64_t>(nr_max, R - ra);
             CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
             CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
-            hipLaunchKernelGGL((separable_hist_kernel<kSepTC, kSepRB>), dim3((nr + kSepRB - 1) / kSepRB, C),
-                               dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(),
-                               cs.group_off_dev.as<int>(), ctx->sep_wr.as<f32x4>() + (size_t)ra * C,
-                               ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(),
-                               ctx->sep_tab.as<unsigned>(), ctx->sep_meta.as<SepMeta>(),
-                               cs.scale_dev.as<double>(), C, nt, nr, ctx->partial_buf.as<double>());
+            if (long_list) launch_separable<2048, 2>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
+            else launch_separable<1024, 4>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
                                0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);
