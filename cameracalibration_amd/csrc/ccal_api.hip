@@ -224,7 +224,7 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     for (auto& s : ctx->sets) s.release();
     DevBuf* bufs[] = {&ctx->w_buf, &ctx->partial_buf, &ctx->cost_buf, &ctx->rec_buf,
                       &ctx->minrec_buf, &ctx->list_buf, &ctx->count_buf, &ctx->mats_buf,
-                      &ctx->planes_buf, &ctx->psum_buf, &ctx->pmax_buf, &ctx->osum_buf,
+                      &ctx->planes_buf, &ctx->psum_buf, &ctx->osum_buf,
                       &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf, &ctx->sep_wr,
                       &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta};
     for (DevBuf* b : bufs) b->release();
