@@ -230,7 +230,9 @@ typedef struct {
     int     converged;
     double  fval;
     double  xval[10];
-    int64_t n_evals;         /* objective evaluations (poses scored) */
+    int64_t n_evals;         /* objective evaluations of the sequential algorithm: 1 + 2*dim per
+                              * iterate and per line-search trial it visits (the library evaluates
+                              * fewer: gradients of trials that fail Armijo are never needed) */
 } ccal_gd_result;
 
 void ccal_gd_default_opts(ccal_gd_opts* o);
