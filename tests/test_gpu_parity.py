@@ -148,6 +148,57 @@ def test_ordered_sum_is_the_sequential_sum(gpu_opt):
         assert gpu_opt.ordered_sum(v) == _seq_sum(v)
 
 
+def test_exact_eval_edge_shapes_and_values(gpu_opt, oracle):
+    """Cloud sizes and offsets that are not multiples of the 8-element runs, clouds of one point,
+    points exactly on the plane (every distance 0: the running sum never leaves zero), one huge
+    distance in the middle of small ones, and a non-finite coordinate: cost, per-cloud mean and
+    maximum stay bit-equal to the oracle (NaN where the oracle says NaN)."""
+    rng = np.random.default_rng(5)
+    eye = np.eye(4).reshape(1, 16)
+    sizes = [1, 7, 9, 511, 513, 1, 4097, 16385, 3]
+    clouds = [rng.normal(0, 0.05, (n, 3)).astype(np.float32) + np.float32([0, 0, 0.3]) for n in sizes]
+    B = np.repeat(eye, len(sizes), axis=0)
+    plane = np.float32([0.01, -0.02, 1.0, -0.3])
+    pose0 = np.zeros(6)
+    poses = pose0 + rng.normal(0, 1, (9, 6)) * np.array([0.004] * 3 + [0.02] * 3)
+    gpu_opt.upload_clouds(0, clouds, B)
+    gpu_opt.set_plane(plane)
+    o = oracle.OracleScene(clouds, B)
+    np.testing.assert_array_equal(gpu_opt.get_error(poses), [o.get_error(p, plane) for p in poses])
+    cost, mean, mx = gpu_opt.per_cloud_error(poses[0])
+    om, ox = o.per_cloud_error(poses[0], plane)
+    np.testing.assert_array_equal(mean, om)
+    np.testing.assert_array_equal(mx, ox)
+
+    # exact zeros, then a spike, then zeros again
+    flat = np.zeros((5000, 3), dtype=np.float32)
+    flat[:, :2] = rng.normal(0, 0.1, (5000, 2)).astype(np.float32)
+    spiky = flat.copy()
+    spiky[2500, 2] = 3.0e7
+    zplane = np.float32([0, 0, 1, 0])
+    gpu_opt.upload_clouds(0, [flat, spiky, flat[:13]], np.repeat(eye, 3, axis=0))
+    gpu_opt.set_plane(zplane)
+    o = oracle.OracleScene([flat, spiky, flat[:13]], np.repeat(eye, 3, axis=0))
+    cost, mean, mx = gpu_opt.per_cloud_error(pose0)
+    om, ox = o.per_cloud_error(pose0, zplane)
+    assert cost == o.get_error(pose0, zplane) and mean[0] == 0.0 and mx[1] == 3.0e7
+    np.testing.assert_array_equal(mean, om)
+    np.testing.assert_array_equal(mx, ox)
+
+    # a NaN and an infinity among ordinary points
+    bad = clouds[3].copy()
+    bad[100, 1] = np.nan
+    worse = clouds[4].copy()
+    worse[7, 0] = np.inf
+    gpu_opt.upload_clouds(0, [clouds[3], bad, worse], np.repeat(eye, 3, axis=0))
+    gpu_opt.set_plane(plane)
+    o = oracle.OracleScene([clouds[3], bad, worse], np.repeat(eye, 3, axis=0))
+    _, mean, _ = gpu_opt.per_cloud_error(poses[1])
+    om, _ = o.per_cloud_error(poses[1], plane)
+    np.testing.assert_array_equal(mean, om)          # NaN == NaN under assert_array_equal
+    assert mean[0] == om[0] and np.isnan(mean[1]) and not np.isfinite(mean[2])
+
+
 def test_exact_eval_large_clouds_bit_equal(gpu_opt, oracle):
     s = make_scene(3, 120000, seed=41, ragged=True)
     upload(gpu_opt, s)
@@ -241,6 +292,33 @@ def test_separable_search_equals_dense(gpu_opt, oracle):
         idx, cost, _, _ = gpu_opt.grid_search(s.pose_init, g)
         oi, oc, _, _ = o.grid_search(s.plane, s.pose_init, og)
         assert (idx, cost) == (oi, oc)
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
+def test_separable_search_degenerate_grids(gpu_opt, oracle):
+    """One translation, one rotation, and a plane whose normal makes whole groups of translations
+    share one constant (identity robot poses, normal along z: x and y shifts do not move the
+    points off the plane): the separable pass still reproduces the dense costs and the winner."""
+    import cameracalibration_amd as cc
+    rng = np.random.default_rng(11)
+    eye = np.eye(4).reshape(1, 16)
+    clouds = [(rng.normal(0, 0.05, (n, 3)) * [1, 1, 0.02] + [0, 0, 0.3]).astype(np.float32) for n in (900, 1500)]
+    B = np.repeat(eye, 2, axis=0)
+    gpu_opt.upload_clouds(0, clouds, B)
+    gpu_opt.set_plane(np.float32([0, 0, 1, -0.3]))
+    base = np.array([0.001, -0.002, 0.0015, 0.01, -0.02, 0.015])
+    try:
+        for counts in ([1, 1, 1, 3, 3, 3], [4, 4, 4, 1, 1, 1], [6, 6, 3, 2, 2, 2], [1, 1, 1, 1, 1, 1]):
+            g = cc.Grid.make([-6] * 3 + [-2] * 3, [3] * 3 + [2] * 3, counts)
+            gpu_opt.set_search_mode(0)
+            dense = gpu_opt.grid_costs(base, g)
+            want = gpu_opt.grid_search(base, g)
+            gpu_opt.set_search_mode(1)
+            sep = gpu_opt.grid_costs(base, g)
+            got = gpu_opt.grid_search(base, g)
+            np.testing.assert_allclose(sep, dense, rtol=FAST_RTOL)
+            assert (got[0], got[1]) == (want[0], want[1])
     finally:
         gpu_opt.set_search_mode(0)
 
