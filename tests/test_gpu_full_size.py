@@ -59,6 +59,17 @@ def test_full_size_search_properties(gpu_opt, ccal, oracle, big):
     w = argmin_merge([p[1] for p in parts], [p[0] for p in parts])
     assert (parts[w][0], parts[w][1]) == (idx, cost) and parts[1][0] == -1
 
+    # the separable pass (one histogram pass per rotation) finds the same winner, and its costs
+    # follow the dense kernel's over a cut of the grid
+    gpu_opt.set_search_mode(1)
+    try:
+        idx_s, cost_s, _, st_s = gpu_opt.grid_search(s.pose_init, g)
+        sep = gpu_opt.grid_costs(s.pose_init, g, 270_000, 281_000)
+    finally:
+        gpu_opt.set_search_mode(0)
+    assert (idx_s, cost_s) == (idx, cost) and st_s.kernel_ms < st.kernel_ms
+    np.testing.assert_allclose(sep, gpu_opt.grid_costs(s.pose_init, g, 270_000, 281_000), rtol=1e-5)
+
     # scaling the plane by 2 scales numerator and |n| exactly: identical costs and winner
     gpu_opt.set_plane(2.0 * s.plane)
     idx2, cost2, _, _ = gpu_opt.grid_search(s.pose_init, g)
