@@ -4,7 +4,7 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): synthetic 20 poses x 300k points per cloud,
+Workload: synthetic 20 poses x 300k points per cloud,
 10^6-candidate combinatorial grid per GPU.  One "step" = one complete discrete
 search over this rank's candidates: candidate 4-vector generation, the batched
 residual kernel over every (candidate, point) pair, split reduction, arg-min,

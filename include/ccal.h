@@ -6,7 +6,7 @@
  * entry point below replaces one of those call seams; the comment above it
  * names the reference lines it stands in for (paths relative to the reference
  * tree).  A host program written against the reference binds these instead of
- * the member functions; see INTEGRATION.md for the call-site patch.
+ * the member functions.
  *
  * Conventions
  *   - every function returns an int status: CCAL_OK (0) or a negative code;
