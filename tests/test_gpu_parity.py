@@ -221,6 +221,12 @@ def test_exact_eval_with_caller_planes(gpu_opt, oracle):
     want = np.array([o.get_error_plane(p, pl) for p, pl in zip(poses, planes)])
     got = gpu_opt.get_error(poses, planes)
     np.testing.assert_array_equal(got, want)
+    # plane norms across the range: the kernel divides through a rounded reciprocal where that is
+    # provably exact and with a plain division elsewhere; the oracle always divides
+    for scale in (1e-160, 1e-95, 1e-30, 3.0e-7, 1.0, 7.0e8, 1e30, 1e95, 1e160):
+        scaled = planes[:5] * scale
+        want = np.array([o.get_error_plane(p, pl) for p, pl in zip(poses[:5], scaled)])
+        np.testing.assert_array_equal(gpu_opt.get_error(poses[:5], scaled), want)
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
