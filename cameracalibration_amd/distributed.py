@@ -22,6 +22,45 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def merge_descents(fvals, xvals, first_start: int, device=None, group=None):
+    """Multi-start refinement sharded over ranks (replicas, no data-path collective): every rank
+    has run the starts [first_start, first_start + len(fvals)) of one global list; the best
+    descent overall -- lowest final cost, lowest start index on ties -- is returned on every
+    rank as (fval, global_start_index, xval).  One all-gather of dim + 2 doubles per rank."""
+    import torch
+    import torch.distributed as dist
+
+    f = np.asarray(fvals, dtype=np.float64)
+    x = np.asarray(xvals, dtype=np.float64).reshape(len(f), -1) if len(f) else np.zeros((0, 0))
+    if len(f):
+        k = int(np.lexsort((np.arange(len(f)), f))[0])
+        rec = np.concatenate([[f[k], float(first_start + k)], x[k]])
+    else:
+        rec = None
+    if not (dist.is_available() and dist.is_initialized()):
+        if rec is None:
+            raise ValueError("merge_descents: no descents")
+        return float(rec[0]), int(rec[1]), rec[2:].copy()
+    world = dist.get_world_size(group)
+    dim = torch.tensor([0 if rec is None else len(rec) - 2], dtype=torch.int64, device=device)
+    dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    width = int(dim.item()) + 2
+    mine = torch.full((width,), float("inf"), dtype=torch.float64, device=device)
+    if rec is not None:
+        mine[: len(rec)] = torch.from_numpy(rec)
+    else:
+        mine[1] = -1.0                                   # an empty shard
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    recs = torch.stack(out).cpu().numpy()
+    valid = recs[:, 1] >= 0
+    if not valid.any():
+        raise ValueError("merge_descents: no descents on any rank")
+    order = np.lexsort((recs[:, 1], recs[:, 0]))
+    w = next(int(i) for i in order if valid[i])
+    return float(recs[w, 0]), int(recs[w, 1]), recs[w, 2:].copy()
+
+
 def merge_argmin(cost: float, index: int, device=None, group=None) -> Tuple[float, int, int]:
     """All-gathers (cost, index) over the default process group and returns
     (best_cost, best_index, winner_rank); index < 0 marks an empty shard.

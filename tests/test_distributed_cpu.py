@@ -89,3 +89,61 @@ def test_shard_ranges_tile_the_grid():
 def test_merge_without_process_group():
     from cameracalibration_amd.distributed import merge_argmin
     assert merge_argmin(0.25, 17) == (0.25, 17, 0)
+
+
+def _gd_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from cameracalibration_amd.distributed import merge_descents, shard_range
+    from cameracalibration_amd.synthetic import make_scene
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = make_scene(2, 120, seed=9)
+        o = O.OracleScene(s.clouds, s.base_T_flange)
+        starts = _starts(s)
+        b, e = shard_range(len(starts), rank, world)
+        opts = O.gd_default_opts()
+        opts.max_iterations = 6
+        rs = [o.gd_minimize(s.plane, x0, opts) for x0 in starts[b:e]]
+        fval, idx, x = merge_descents([r.fval for r in rs], [list(r.xval[:6]) for r in rs], b)
+        ret[rank] = (fval, idx, tuple(x))
+    finally:
+        dist.destroy_process_group()
+
+
+def _starts(s):
+    rng = np.random.default_rng(2)
+    st = s.pose_true + rng.uniform(-1, 1, (5, 6)) * np.array([0.004] * 3 + [0.02] * 3)
+    return np.concatenate([st, st[1:2]])                 # a duplicate start: equal cost, higher index
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_multi_start_descent(world, oracle):
+    """Restarts sharded over ranks (the CPU oracle standing in for the GPU call): every rank ends
+    with the best descent of the whole list, the lower start index winning a tie."""
+    from cameracalibration_amd.synthetic import make_scene
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gd_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    s = make_scene(2, 120, seed=9)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    opts = oracle.gd_default_opts()
+    opts.max_iterations = 6
+    rs = [o.gd_minimize(s.plane, x0, opts) for x0 in _starts(s)]
+    f = np.array([r.fval for r in rs])
+    k = int(np.lexsort((np.arange(len(f)), f))[0])
+    results = [ret[r] for r in range(world)]
+    assert len(set(results)) == 1, "ranks disagree on the merged result"
+    assert results[0][0] == f[k] and results[0][1] == k
+    assert results[0][2] == tuple(rs[k].xval[:6])
+    assert rs[1].fval == rs[5].fval and k != 5
+
+
+def test_merge_descents_without_process_group():
+    from cameracalibration_amd.distributed import merge_descents
+    f, i, x = merge_descents([0.5, 0.25, 0.25], [[1] * 6, [2] * 6, [3] * 6], 10)
+    assert (f, i, list(x)) == (0.25, 11, [2.0] * 6)
