@@ -33,6 +33,25 @@ int fail(ccal_ctx* ctx, int code, const std::string& msg)
                         std::string(#expr) + ": " + hipGetErrorString(e__));             \
     } while (0)
 
+// HIP events that are destroyed on every way out of a function.
+struct Events {
+    std::vector<hipEvent_t> e;
+    hipError_t create(size_t n)
+    {
+        e.assign(n, nullptr);
+        for (auto& ev : e) {
+            hipError_t rc = hipEventCreate(&ev);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }
+    hipEvent_t operator[](size_t i) const { return e[i]; }
+    ~Events() { for (auto ev : e) if (ev) (void)hipEventDestroy(ev); }
+    Events() = default;
+    Events(const Events&) = delete;
+    Events& operator=(const Events&) = delete;
+};
+
 int bind(ccal_ctx* ctx)
 {
     CCAL_HIP(ctx, hipSetDevice(ctx->device));
@@ -784,11 +803,10 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     std::vector<unsigned> tab;
     std::vector<SepMeta> meta(C);
     std::vector<std::pair<float, int>> order;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    CCAL_HIP(ctx, hipEventCreate(&e0));
-    CCAL_HIP(ctx, hipEventCreate(&e1));
-    int rc = CCAL_OK;
-    for (int64_t ta = t0; ta < t1 && rc == CCAL_OK; ta += tc) {
+    Events ev;
+    CCAL_HIP(ctx, ev.create(2));
+    const hipEvent_t e0 = ev[0], e1 = ev[1];
+    for (int64_t ta = t0; ta < t1; ta += tc) {
         const int nt = (int)std::min<int64_t>(tc, t1 - ta);
         sb.assign((size_t)C * nt, 0.f);
         perm.assign((size_t)C * nt, 0);
@@ -848,9 +866,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             if (launches) ++*launches;
         }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return rc;
+    return CCAL_OK;
 }
 
 // Fast-path costs of grid candidates [begin, end) into device memory (*cost_local points at
@@ -903,28 +919,22 @@ static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_p
 
     const int64_t chunk = fast_chunk(cs);
     const int n_chunks = (int)((n_local + chunk - 1) / chunk);
-    std::vector<hipEvent_t> evs((size_t)n_chunks * 2, nullptr);
-    for (auto& e : evs) CCAL_HIP(ctx, hipEventCreate(&e));
-    auto free_events = [&]() { for (auto& e : evs) if (e) (void)hipEventDestroy(e); };
+    Events evs;
+    CCAL_HIP(ctx, evs.create((size_t)n_chunks * 2));
     for (int ci = 0; ci < n_chunks; ++ci) {
         const int64_t c0 = (int64_t)ci * chunk;
         const int64_t n = std::min(chunk, n_local - c0);
         gt.first = begin + c0;
         if (int rc = run_fast_chunk(ctx, cs, gt, n, ctx->cost_buf.as<float>() + c0, evs[2 * ci],
-                                    evs[2 * ci + 1])) {
-            free_events();
+                                    evs[2 * ci + 1]))
             return rc;
-        }
     }
     // the table upload above reads `tbl`, and the event times are wanted now
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess)
-        for (int ci = 0; ci < n_chunks; ++ci) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, evs[2 * ci], evs[2 * ci + 1]) == hipSuccess) *kernel_ms += ms;
-        }
-    free_events();
-    CCAL_HIP(ctx, e);
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, evs[2 * ci], evs[2 * ci + 1]) == hipSuccess) *kernel_ms += ms;
+    }
     *launches = n_chunks;
     return CCAL_OK;
 }
@@ -978,18 +988,15 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     if (int rc = bind(ctx)) return rc;
     const CloudSet& cs = ctx->sets[which];
 
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    CCAL_HIP(ctx, hipEventCreate(&ev_begin));
-    CCAL_HIP(ctx, hipEventCreate(&ev_end));
-    auto free_events = [&]() { (void)hipEventDestroy(ev_begin); (void)hipEventDestroy(ev_end); };
+    Events ev;
+    CCAL_HIP(ctx, ev.create(2));
+    const hipEvent_t ev_begin = ev[0], ev_end = ev[1];
     CCAL_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
     float* cost_local = nullptr;
     double kernel_ms = 0.0;
     int launches = 0;
-    if (int rc = grid_fast_pass(ctx, cs, base_pose, g, begin, end, &cost_local, &kernel_ms, &launches)) {
-        free_events();
+    if (int rc = grid_fast_pass(ctx, cs, base_pose, g, begin, end, &cost_local, &kernel_ms, &launches))
         return rc;
-    }
 
     // arg-min and near-minimum band over the local cost array
     const int n_stage1 = (int)std::min<int64_t>(1024, (n_local + 255) / 256);
@@ -1017,7 +1024,6 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float total_ms = 0.f;
     (void)hipEventElapsedTime(&total_ms, ev_begin, ev_end);
-    free_events();
 
     if (!(mn.cost < std::numeric_limits<float>::infinity()) || mn.index < 0)
         return fail(ctx, CCAL_ERR_DEVICE, "grid_search: non-finite costs on the fast path");
