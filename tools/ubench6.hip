@@ -53,7 +53,7 @@ int main()
 {
     double* out; CHECK(hipMalloc(&out, 1 << 24));
     const int iters = 20000;
-    for (int wps = 1; wps <= 4; wps *= 2) {
+    for (int wps = 1; wps <= 8; wps *= 2) {
         int blocks = 256 * wps;
         auto cyc = [&](double ms) { return ms * 1e-3 * 2.4e9 / ((double)iters * 32 * wps); };
         printf("wps %d cycles/wave-instr/SIMD: add_f64 %.2f mul_f64 %.2f fma_f64 %.2f lshl_add_u64 %.2f max_f64 %.2f cmp_f64 %.2f cvt_f32_f64 %.2f cvt_f64_f32 %.2f\n", wps,
