@@ -1491,9 +1491,10 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
 // the L2 caches together.  Results are stored pose-major: out[k * n_clouds + j];
 // out_max may be null when kWantMax is false.  W waves per workgroup: few chains want
 // many waves each (latency), many chains want small workgroups that overlap each
-// other's barriers and segment walks (throughput).
+// other's barriers and segment walks (throughput).  Five waves per SIMD (96 VGPRs, no
+// spills) measured 4 % faster than four; six spill.
 template <int W, bool kWantMax>
-__global__ __launch_bounds__(64 * W) void exact_chain_kernel(
+__global__ __launch_bounds__(64 * W, 5) void exact_chain_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const int64_t* __restrict__ cloud_pt_off, const double* __restrict__ mats,
     const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
