@@ -247,6 +247,8 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
                       &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf, &ctx->sep_wr,
                       &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta};
     for (DevBuf* b : bufs) b->release();
+    ctx->exact_in.release();
+    ctx->exact_out.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;
@@ -460,30 +462,37 @@ extern "C" int ccal_get_plane(const ccal_ctx* ctx, float plane[4])
 // exact objective
 // ---------------------------------------------------------------------------
 
+struct ExactTables {
+    const double* mats;     // [pose][cloud][12]
+    const double* planes;   // [pose][kPlaneStride]
+    double* sum;            // [pose][cloud]
+    double* max;            // [pose][cloud] or null
+};
+
 template <int W, bool kWantMax>
-static void launch_exact_chains_w(ccal_ctx* ctx, const CloudSet& cs, int n_poses)
+static void launch_exact_chains_w(ccal_ctx* ctx, const CloudSet& cs, int n_poses, const ExactTables& t)
 {
     hipLaunchKernelGGL((exact_chain_kernel<W, kWantMax>), dim3(n_poses * cs.n_clouds), dim3(64 * W), 0,
                        ctx->stream, cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                       cs.cloud_pt_off_dev.as<int64_t>(), ctx->mats_buf.as<double>(),
-                       ctx->planes_buf.as<double>(), n_poses, cs.n_clouds, (int64_t)cs.total_pts,
-                       ctx->osum_buf.as<double>(), kWantMax ? ctx->omax_buf.as<double>() : nullptr);
+                       cs.cloud_pt_off_dev.as<int64_t>(), t.mats, t.planes, n_poses, cs.n_clouds,
+                       (int64_t)cs.total_pts, t.sum, kWantMax ? t.max : nullptr);
 }
 
 // Workgroup width by chain count (measured on 20 x 300k points: 16 waves win below ~128
 // chains, 8 up to ~512, 4 beyond).
-static void launch_exact_chains(ccal_ctx* ctx, const CloudSet& cs, int n_poses, bool want_max)
+static void launch_exact_chains(ccal_ctx* ctx, const CloudSet& cs, int n_poses, bool want_max,
+                                const ExactTables& t)
 {
     const int64_t chains = (int64_t)n_poses * cs.n_clouds;
     const int64_t per_cu = chains / std::max(1, ctx->n_cu);
     if (want_max) {
-        if (per_cu < 1) launch_exact_chains_w<16, true>(ctx, cs, n_poses);
-        else if (per_cu < 2) launch_exact_chains_w<8, true>(ctx, cs, n_poses);
-        else launch_exact_chains_w<4, true>(ctx, cs, n_poses);
+        if (per_cu < 1) launch_exact_chains_w<16, true>(ctx, cs, n_poses, t);
+        else if (per_cu < 2) launch_exact_chains_w<8, true>(ctx, cs, n_poses, t);
+        else launch_exact_chains_w<4, true>(ctx, cs, n_poses, t);
     } else {
-        if (per_cu < 1) launch_exact_chains_w<16, false>(ctx, cs, n_poses);
-        else if (per_cu < 2) launch_exact_chains_w<8, false>(ctx, cs, n_poses);
-        else launch_exact_chains_w<4, false>(ctx, cs, n_poses);
+        if (per_cu < 1) launch_exact_chains_w<16, false>(ctx, cs, n_poses, t);
+        else if (per_cu < 2) launch_exact_chains_w<8, false>(ctx, cs, n_poses, t);
+        else launch_exact_chains_w<4, false>(ctx, cs, n_poses, t);
     }
 }
 
@@ -502,17 +511,22 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
 
     // one workgroup per (cloud, pose) chain; the batch bound only keeps the grid and the
     // constant tables modest
+    // Pose tables and results live in pinned host memory that the kernel addresses directly: a
+    // request is one launch and one stream wait, with no copy call on either side.
     const int max_batch = 4096;
-    std::vector<double> mats, planes, hsum, hmax;
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
         const int nb = std::min(max_batch, n_poses - k0);
-        const int pb = nb;
-        mats.assign((size_t)pb * C * 12, 0.0);
-        planes.assign((size_t)pb * kPlaneStride, 0.0);
-        for (int k = 0; k < pb; ++k) {
+        const size_t n_mats = (size_t)nb * C * 12, n_planes = (size_t)nb * kPlaneStride, n_out = (size_t)nb * C;
+        CCAL_HIP(ctx, ctx->exact_in.ensure((n_mats + n_planes) * sizeof(double)));
+        CCAL_HIP(ctx, ctx->exact_out.ensure(2 * n_out * sizeof(double)));
+        double* mats = ctx->exact_in.as<double>();
+        double* planes = mats + n_mats;
+        double* hsum = ctx->exact_out.as<double>();
+        double* hmax = hsum + n_out;
+        for (int k = 0; k < nb; ++k) {
             const int src = k0 + k;
-            pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data() + (size_t)k * C * 12);
-            double* pl = planes.data() + (size_t)k * kPlaneStride;
+            pose_matrices(cs, poses6 + 6 * (size_t)src, mats + (size_t)k * C * 12);
+            double* pl = planes + (size_t)k * kPlaneStride;
             if (planes4) {
                 for (int e = 0; e < 4; ++e) pl[e] = planes4[4 * (size_t)src + e];
             } else {
@@ -522,25 +536,10 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
             pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
             pl[5] = 1.0 / pl[4];
             pl[6] = (pl[4] > 0x1p-300 && pl[4] < 0x1p300) ? 1.0 : 0.0;
+            pl[7] = 0.0;
         }
-        CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
-        CCAL_HIP(ctx, ctx->planes_buf.ensure(planes.size() * sizeof(double)));
-        CCAL_HIP(ctx, ctx->osum_buf.ensure((size_t)pb * C * sizeof(double)));
-        CCAL_HIP(ctx, ctx->omax_buf.ensure((size_t)pb * C * sizeof(double)));
-        CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
-                                     hipMemcpyHostToDevice, ctx->stream));
-        CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, planes.data(),
-                                     planes.size() * sizeof(double), hipMemcpyHostToDevice,
-                                     ctx->stream));
-        launch_exact_chains(ctx, cs, pb, per_cloud_max != nullptr);
+        launch_exact_chains(ctx, cs, nb, per_cloud_max != nullptr, ExactTables{mats, planes, hsum, hmax});
         CCAL_HIP(ctx, hipGetLastError());
-        hsum.resize((size_t)pb * C);
-        hmax.resize((size_t)pb * C);
-        CCAL_HIP(ctx, hipMemcpyAsync(hsum.data(), ctx->osum_buf.p, hsum.size() * sizeof(double),
-                                     hipMemcpyDeviceToHost, ctx->stream));
-        if (per_cloud_max)
-            CCAL_HIP(ctx, hipMemcpyAsync(hmax.data(), ctx->omax_buf.p, hmax.size() * sizeof(double),
-                                         hipMemcpyDeviceToHost, ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < nb; ++k) {
             double error = 0.0;

@@ -36,6 +36,29 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Grow-only pinned host allocation; the pointer is valid in kernels too (small tables the
+// device reads once and result words it writes once, without a copy call on either side).
+struct HostBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        size_t want = need + need / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct CloudSet {
     bool ready = false;
     int n_clouds = 0;
@@ -83,6 +106,7 @@ struct ccal_ctx {
     // scratch (grow-only)
     ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
     ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
+    ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
     ccal::DevBuf mats_buf, planes_buf, psum_buf, osum_buf, omax_buf, tbl_buf, dist_buf;
 };
 
