@@ -9,3 +9,6 @@ opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
 o = cc.GdOptions.default()
 t = time.time(); r = opt.gradient_descent(s.pose_init, o); print("gd", r.iterations, r.n_evals, r.fval, time.time() - t, flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "10":
+    x0 = np.concatenate([r.xval, s.plane.astype(np.float64)])
+    t = time.time(); r10 = opt.gradient_descent(x0, o); print("gd10", r10.iterations, r10.n_evals, r10.fval, time.time() - t, flush=True)
