@@ -182,3 +182,53 @@ def test_parsers(oracle):
     assert d[3] == 10 * 3.141592 / 180 and d[4] == -2 * 3.141592 / 180
     assert oracle.file_id("../example/calib_1/pointcloud/cloud_3.ply") == 3
     assert oracle.file_id("pos_12.pcd") == 12
+
+
+def _numpy_get_error(clouds, base_T_flange, pose, plane, pose_to_matrix):
+    """Second, independent statement of getError (src/camera_calibration_optimization.cpp:280-313)
+    in vectorised numpy FP64 with the same operation order: M = B*F accumulated k = 0..3 from
+    zero (:290), the SSE2 transform order ((c3 + x c0) + y c1) + z c2 rounded to float
+    (src/helpers.hpp:139-151), fabs(a x + b y + c z + d) / sqrt(a^2 + b^2 + c^2) (:121-124),
+    distances added one by one (np.cumsum is a left-to-right running sum), mean per cloud,
+    mean over clouds (:309-312)."""
+    F = pose_to_matrix(pose)
+    pl = np.asarray(plane, dtype=np.float32).astype(np.float64)
+    norm = np.sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2])
+    error = 0.0
+    for cloud, B in zip(clouds, np.asarray(base_T_flange, dtype=np.float64).reshape(-1, 4, 4)):
+        M = np.zeros((4, 4))
+        for i in range(4):
+            for j in range(4):
+                acc = 0.0
+                for k in range(4):
+                    acc = acc + B[i, k] * F[k, j]
+                M[i, j] = acc
+        p = np.asarray(cloud, dtype=np.float32).astype(np.float64)
+        q = []
+        for r in range(3):
+            acc = p[:, 0] * M[r, 0] + M[r, 3]
+            acc = p[:, 1] * M[r, 1] + acc
+            acc = p[:, 2] * M[r, 2] + acc
+            q.append(acc.astype(np.float32).astype(np.float64))
+        d = np.abs(pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3]) / norm
+        error += np.cumsum(d)[-1] / len(d)
+    return error / len(clouds)
+
+
+def test_numpy_restatement_agrees_with_c_oracle(oracle, calib1):
+    """Two independent transcriptions of the objective agree bit for bit (the reference itself
+    cannot be run here, so this guards the oracle against a transcription slip)."""
+    from cameracalibration_amd.synthetic import make_scene
+    ds = [calib1["ds_%d" % i] for i in range(4)]
+    sc = oracle.OracleScene(ds, calib1["base_T_flange"])
+    rng = np.random.default_rng(8)
+    for _ in range(6):
+        pose = calib1["pose_init"] + rng.normal(0, 1, 6) * np.array([0.004] * 3 + [0.02] * 3)
+        want = sc.get_error(pose, calib1["plane_full"])
+        got = _numpy_get_error(ds, calib1["base_T_flange"], pose, calib1["plane_full"], oracle.pose_to_matrix)
+        assert got == want
+    s = make_scene(3, 5000, seed=31, ragged=True)
+    sc = oracle.OracleScene(s.clouds, s.base_T_flange)
+    for pose in (s.pose_init, s.pose_true):
+        assert _numpy_get_error(s.clouds, s.base_T_flange, pose, s.plane, oracle.pose_to_matrix) == \
+            sc.get_error(pose, s.plane)
