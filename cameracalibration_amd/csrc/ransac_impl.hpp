@@ -158,6 +158,9 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                 best_h = h;
             }
         }
+        // leaders come in ascending index: once a hypothesis holds every point no later one can
+        // win (clean data makes all hypotheses tie; this stops after the first pass)
+        if (best_cnt == (unsigned long long)cs.total_pts) break;
     }
 
     // 4. refit on the winner's inliers
