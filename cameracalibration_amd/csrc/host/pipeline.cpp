@@ -12,7 +12,10 @@
 #include "cloud_io.hpp"
 #include "xml_lite.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -64,15 +67,39 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
     if (!clouds || clouds->children.empty()) throw std::runtime_error("config: no data.camera.clouds entries");
 
     std::vector<int> mapping;
+    std::vector<std::string> filenames;
     for (const auto& c : clouds->children) {                                       // :158
         const std::string filename = trim(c->text);
         const int cloud_id = file_id(filename);                                    // :161
         if (chatty) std::cout << "Cloud Number: " << cloud_id << std::endl;
         mapping.push_back(cloud_id - 1);                                           // :163
-        Cloud all = read_point_cloud(filename, camera_metric);                     // :165
-        Cloud kept = filter_z(all, 0.8f);                                          // :167-169
-        if (kept.empty()) throw std::runtime_error(filename + ": no points with z <= 0.8");
-        in.raw.push_back(std::move(kept));   // the voxel grid of :199-203 runs on the device after the upload
+        filenames.push_back(filename);
+    }
+    // read (:165) and drop z > 0.8 / NaN (:167-169); the files are independent, so a few host
+    // threads take them in turn.  The first failing file in document order is the one reported.
+    // The voxel grid of :199-203 runs on the device after the upload.
+    in.raw.resize(filenames.size());
+    {
+        std::vector<std::exception_ptr> errors(filenames.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t k = next++; k < filenames.size(); k = next++) {
+                try {
+                    Cloud kept = filter_z(read_point_cloud(filenames[k], camera_metric), 0.8f);
+                    if (kept.empty()) throw std::runtime_error(filenames[k] + ": no points with z <= 0.8");
+                    in.raw[k] = std::move(kept);
+                } catch (...) {
+                    errors[k] = std::current_exception();
+                }
+            }
+        };
+        const size_t n_threads = std::min<size_t>({filenames.size(), 8, std::max(1u, std::thread::hardware_concurrency())});
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        for (auto& e : errors)
+            if (e) std::rethrow_exception(e);
     }
 
     const XmlNode* ik = root->find("data.camera.transformations.inverse_kinematics.location");
