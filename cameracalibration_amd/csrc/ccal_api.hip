@@ -12,8 +12,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <limits>
 #include <new>
+#include <thread>
 
 using namespace ccal;
 
@@ -51,6 +53,19 @@ struct Events {
     Events(const Events&) = delete;
     Events& operator=(const Events&) = delete;
 };
+
+// fn(j) for j in [0, n) on a few host threads (clouds are independent units of host work).
+template <typename Fn>
+void parallel_over(int n, Fn fn)
+{
+    const int n_threads = (int)std::min<size_t>({(size_t)n, 8, std::max(1u, std::thread::hardware_concurrency())});
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int j = next++; j < n; j = next++) fn(j); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
 
 int bind(ccal_ctx* ctx)
 {
@@ -304,14 +319,21 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     std::vector<float> hx(total), hy(total), hz(total);
     std::vector<BlockDesc> blocks;
     cs.cloud_block_off.assign(n_clouds + 1, 0);
+    {
+        std::vector<size_t> offs(n_clouds, 0);
+        for (int j = 1; j < n_clouds; ++j) offs[j] = offs[j - 1] + n_pts[j - 1];
+        parallel_over(n_clouds, [&](int j) {
+            const float* p = xyz[j];
+            const size_t o = offs[j];
+            for (size_t i = 0; i < n_pts[j]; ++i) {
+                hx[o + i] = p[3 * i + 0];
+                hy[o + i] = p[3 * i + 1];
+                hz[o + i] = p[3 * i + 2];
+            }
+        });
+    }
     size_t off = 0;
     for (int j = 0; j < n_clouds; ++j) {
-        const float* p = xyz[j];
-        for (size_t i = 0; i < n_pts[j]; ++i) {
-            hx[off + i] = p[3 * i + 0];
-            hy[off + i] = p[3 * i + 1];
-            hz[off + i] = p[3 * i + 2];
-        }
         cs.cloud_block_off[j] = (int)blocks.size();
         for (size_t b = 0; b < n_pts[j]; b += kPointsPerBlock) {
             BlockDesc bd;
@@ -367,7 +389,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
 
     std::vector<float> hg((size_t)n_groups * 256, 0.0f);
     std::vector<double> scale(n_clouds);
-    for (int j = 0; j < n_clouds; ++j) {
+    parallel_over(n_clouds, [&](int j) {
         const float* p = xyz[j];
         const size_t n = n_pts[j];
         double c[3] = {0, 0, 0};
@@ -392,7 +414,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             gp[(2 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 2] - c[2]);
             gp[(3 * 16 + col) * 4 + u] = 1.0f;
         }
-    }
+    });
     CCAL_HIP(ctx, cs.groups.ensure(hg.size() * sizeof(float)));
     CCAL_HIP(ctx, cs.group_off_dev.ensure((n_clouds + 1) * sizeof(int)));
     CCAL_HIP(ctx, cs.scale_dev.ensure(n_clouds * sizeof(double)));
