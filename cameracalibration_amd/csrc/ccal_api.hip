@@ -735,9 +735,9 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
 // ---------------------------------------------------------------------------
 // separable search: all translations of a rotation from one pass over the points
 // ---------------------------------------------------------------------------
-// Translations per launch (histogram bins in LDS) x rotations per workgroup: 1024 x 4 when one
-// launch holds all translations (57 KB of LDS); 2048 x 2 for longer lists, which halves the
-// number of passes over the points (73 KB).
+// Translations per launch (histogram bins in LDS) x rotations per workgroup: 1024 x 2 when one
+// launch holds all translations (37 KB of LDS; 2 rotations measured 10 % faster than 4 or 8);
+// 2048 x 2 for longer lists, which halves the number of passes over the points (73 KB).
 template <int TC, int RB>
 static void launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr)
 {
@@ -817,7 +817,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
                                  ctx->stream));
 
     const bool long_list = t1 - t0 > 1024;
-    const int tc = long_list ? 2048 : 1024, rb = long_list ? 2 : 4;
+    const int tc = long_list ? 2048 : 1024, rb = 2;
     const int M = 2 * tc;
     std::vector<float> sb;
     std::vector<int> perm;
@@ -875,7 +875,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
             CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
             if (long_list) launch_separable<2048, 2>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
-            else launch_separable<1024, 4>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
+            else launch_separable<1024, 2>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
                                0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);
