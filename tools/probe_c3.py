@@ -1,4 +1,5 @@
-"""One-off scale check at the C3 size (100 clouds x 1e6 points, 1e7-candidate grid)."""
+"""One-off scale check at the C3 size (100 clouds x 1e6 points, 1e7-candidate grid; other grid
+counts as a third argument, e.g. 20,20,25,20,20,25 for the 1e8-candidate C4 grid)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,11 +9,11 @@ nc, npts = int(sys.argv[1]), int(sys.argv[2])
 t = time.time(); s = make_scene(nc, npts); print(f"scene {time.time()-t:.1f} s", flush=True)
 opt = cc.Optimizer(0)
 t = time.time(); opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane); print(f"upload {time.time()-t:.1f} s", flush=True)
-counts = [20, 20, 25, 10, 10, 10]
+counts = [int(c) for c in sys.argv[3].split(",")] if len(sys.argv) > 3 else [20, 20, 25, 10, 10, 10]
 g = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (c - 1) for c in counts[:3]] + [10.0 / (c - 1) for c in counts[3:]], counts)
 opt.set_search_mode(1)
 t = time.time(); idx, cost, pose, st = opt.grid_search(s.pose_init, g); dt = time.time() - t
-print(f"separable 1e7 candidates: idx {idx} cost {cost:.9g} wall {dt:.2f} s kernel {st.kernel_ms:.0f} ms launches {st.kernel_launches} rescored {st.n_rescored}", flush=True)
+print(f"separable {g.size:.3g} candidates: idx {idx} cost {cost:.9g} wall {dt:.2f} s kernel {st.kernel_ms:.0f} ms launches {st.kernel_launches} rescored {st.n_rescored}", flush=True)
 opt.set_search_mode(0)
 n = 200000
 b = max(0, idx - n // 2)
