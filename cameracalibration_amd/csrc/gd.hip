@@ -60,6 +60,7 @@ struct Machine {
     bool first_request = true;
     static constexpr int kMaxSpeculated = 64;
     int64_t n_main_hits = 0;
+    bool ride_along = true;   // off for the rest of a line search whose curvature test has failed once
     int chains_per_pose = 0, round_chains = 0;   // set for a single descent: clouds, compute units
 
     int stencil() const { return 1 + 2 * D; }
@@ -102,7 +103,7 @@ struct Machine {
     int request_points() const
     {
         if (phase == MAIN) return stencil();
-        if (phase == TRIAL_G) return 2 * D + stencil();
+        if (phase == TRIAL_G) return 2 * D + (ride_along ? stencil() : 0);
         return planned_trials();
     }
 
@@ -158,6 +159,7 @@ struct Machine {
             // next iteration's main stencil rides along with its gradient points
             double xs[10];
             emit_axis_points(xn, out);
+            if (!ride_along) return;
             next_main_point(xs);
             std::memcpy(out + (size_t)2 * D * D, xs, sizeof(double) * D);
             emit_axis_points(xs, out + (size_t)(2 * D + 1) * D);
@@ -217,7 +219,7 @@ struct Machine {
         ++ls_it;
         ++n_trials;
         n_evals += stencil();
-        if (!wolfe) ++n_wolfe_only_fail;
+        if (!wolfe) { ++n_wolfe_only_fail; ride_along = false; }
         if (!wolfe && trial_allowed()) { next_trial(); return false; }
         finish_iteration();
         return true;
@@ -236,6 +238,7 @@ struct Machine {
         alpha = o.wolfe_max_step / o.wolfe_decrease;
         ls_it = 0;
         first_request = true;
+        ride_along = true;
         if (trial_allowed()) next_trial();
         else finish_iteration();
     }
@@ -255,7 +258,8 @@ struct Machine {
             next_main_point(xs);
             gradient_of(f, g);
             first_request = false;
-            if (conclude_trial(g) && phase == MAIN && std::memcmp(xs, x, sizeof(double) * D) == 0) {
+            const bool rode = ride_along;
+            if (conclude_trial(g) && rode && phase == MAIN && std::memcmp(xs, x, sizeof(double) * D) == 0) {
                 ++n_main_hits;
                 feed_main(f + 2 * D);   // the stencil that rode along is the one now due
             }

@@ -442,6 +442,39 @@ def test_gradient_descent_matches_oracle(gpu_opt, oracle, calib1):
     assert [r10.iterations, int(r10.converged), r10.n_evals] == list(calib1["gd10_it"])
 
 
+@pytest.mark.parametrize("tweak", ["curvature_never", "curvature_rarely", "armijo_never", "capped_trials",
+                                   "no_momentum_big_eps"])
+def test_gradient_descent_line_search_branches(gpu_opt, oracle, tweak):
+    """Option sets that drive the line search through its rare branches -- the curvature test
+    failing after Armijo passed, no trial ever accepted (down to the minimum step), the trial
+    cap -- still give the oracle's iterates, counts and values bit for bit."""
+    import cameracalibration_amd as cc
+    s = make_scene(3, 700, seed=17, ragged=True)
+    upload(gpu_opt, s)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    go, oo = cc.GdOptions.default(), oracle.gd_default_opts()
+    for opts in (go, oo):
+        opts.max_iterations = 14
+        if tweak == "curvature_never":
+            opts.wolfe_c2 = -1.0                 # g.g_new <= -g.g never holds near the start
+            opts.wolfe_min_step = 1e-4           # bounds the backtracking
+        elif tweak == "curvature_rarely":
+            opts.wolfe_c2 = 0.2
+            opts.wolfe_min_step = 1e-6
+        elif tweak == "armijo_never":
+            opts.wolfe_c1 = 1e6
+            opts.wolfe_min_step = 1e-5
+        elif tweak == "capped_trials":
+            opts.wolfe_max_it = 5
+        elif tweak == "no_momentum_big_eps":
+            opts.momentum = 0.0
+            opts.fd_eps = 1e-5
+    r = gpu_opt.gradient_descent(s.pose_init, go)
+    w = o.gd_minimize(s.plane, s.pose_init, oo)
+    np.testing.assert_array_equal(r.xval, np.array(w.xval[:6]))
+    assert (r.iterations, r.converged, r.n_evals, r.fval) == (w.iterations, bool(w.converged), w.n_evals, w.fval)
+
+
 def test_multi_start_gd_equals_single_starts(gpu_opt):
     s = make_scene(3, 400, seed=8)
     upload(gpu_opt, s)
