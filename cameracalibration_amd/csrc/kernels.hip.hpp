@@ -1,17 +1,19 @@
 // kernels.hip.hpp -- gfx950 kernels of the calibration hot path.
 //
-// Two arithmetic families:
+// Arithmetic families:
 //   * "fast": FP32, the point-to-plane residual folded into a 4-vector per
 //     (candidate, cloud) and contracted with homogeneous points on the matrix
 //     cores: v_mfma_f32_16x16x4_f32 is exactly a K=4 contraction of a
 //     16-candidate tile with a 16-point tile, bit-identical to an fmaf chain.
 //     |.| and the running sum are VALU adds on the MFMA result.
 //   * "exact": the reference's own arithmetic (FP64 SE3 apply in the SSE2
-//     summation order, point rounded to float, FP64 distance with a true
-//     division, distances of a cloud added one by one in point order), used for
-//     single poses, finite-difference stencils, the error report and for
-//     re-scoring near-minimum grid candidates.  Its results are bit-identical
-//     to the CPU evaluation of the same lines.
+//     summation order, point rounded to float, FP64 distance with a correctly
+//     rounded division, distances of a cloud added one by one in point order),
+//     used for single poses, finite-difference stencils, the error report and
+//     for re-scoring near-minimum grid candidates.  Its results are
+//     bit-identical to the CPU evaluation of the same lines.
+//   * "separable": for product grids, all translations of a rotation from one
+//     histogram pass over the points (fast-path accuracy, integer sums).
 //
 // Included once by ccal_api.hip; everything here is internal.
 #pragma once
