@@ -74,3 +74,27 @@ def test_gd_default_options(ccal):
     assert (o.max_iterations, o.min_gradient_len, o.min_step_len, o.momentum) == (10000, 1e-6, 1e-6, 0.4)
     assert o.fd_eps == np.sqrt(np.finfo(np.float64).eps)
     assert (o.wolfe_decrease, o.wolfe_c1, o.wolfe_c2) == (0.8, 1e-4, 0.9)
+
+
+def test_header_is_plain_c_and_links(tmp_path, ccal):
+    """include/ccal.h compiles as C99 and as C++11, and a C program links against libccal.so
+    by the header's declarations alone (no GPU call is made)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_ccal.c"
+    src.write_text(
+        '#include "ccal.h"\n'
+        "int main(void) {\n"
+        "    ccal_grid g; ccal_gd_opts o; double pose[6] = {0}, T[16];\n"
+        "    ccal_grid_default(&g); ccal_gd_default_opts(&o); ccal_pose_to_matrix(pose, T);\n"
+        "    return !(ccal_grid_size(&g) == 1771561 && o.max_iterations == 10000 && T[0] == 1.0 &&\n"
+        "             ccal_status_string(CCAL_OK) != 0);\n"
+        "}\n")
+    inc = os.path.join(root, "include")
+    libdir = os.path.join(root, "cameracalibration_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+    exe = tmp_path / "use_ccal"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lccal",
+                           "-Wl,-rpath," + libdir])
+    assert subprocess.run([str(exe)]).returncode == 0
