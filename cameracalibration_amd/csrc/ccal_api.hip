@@ -1133,7 +1133,7 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
                        cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
                        org[2], InlierMask{{0, 0, 0, 0, 1}, -1.0}, ctx->psum_buf.as<double>());
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3(kMoments), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
     double m[kMoments];

@@ -1598,15 +1598,34 @@ __global__ __launch_bounds__(256) void moments_kernel(
     }
 }
 
-__global__ __launch_bounds__(64) void moments_finalize_kernel(const double* __restrict__ part,
-                                                              int n_blocks,
-                                                              double* __restrict__ out)
+// Sums the per-block partial moments in a fixed order (one workgroup: thread t takes rows
+// t, t + 1024, ...; then a wave tree and the 16 wave totals in wave order).
+__global__ __launch_bounds__(1024) void moments_finalize_kernel(const double* __restrict__ part,
+                                                                int n_blocks,
+                                                                double* __restrict__ out)
 {
-    const int k = blockIdx.x;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < n_blocks; b += 64) s += part[(int64_t)b * kMoments + k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) out[k] = s;
+    __shared__ double red[16][kMoments];
+    double m[kMoments];
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) m[k] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 1024) {
+        const double* row = part + (int64_t)b * kMoments;
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) m[k] += row[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+        double s = m[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------
