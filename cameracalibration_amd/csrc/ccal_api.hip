@@ -262,6 +262,7 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
                       &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf, &ctx->sep_wr,
                       &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta};
     for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : ctx->vox) b.release();
     ctx->exact_in.release();
     ctx->exact_out.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

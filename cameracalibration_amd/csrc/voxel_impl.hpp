@@ -52,6 +52,7 @@ struct VoxelDims {
     float inv;
     float minb[3];
     long long div0, div01;
+    unsigned long long nonfinite_key;   // one past the last cell: sorts last with the fewest key bits
 };
 
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xs,
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float x = xs[begin + i], y = ys[begin + i], z = zs[begin + i];
-    unsigned long long key = ~0ull;   // non-finite points sort last and are dropped
+    unsigned long long key = d.nonfinite_key;   // non-finite points sort last and are dropped
     if (__builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z)) {
         const long long i0 = (long long)(floorf(x * d.inv) - d.minb[0]);
         const long long i1 = (long long)(floorf(y * d.inv) - d.minb[1]);
@@ -75,21 +76,43 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict
     idx[i] = (unsigned int)i;
 }
 
-// One thread per voxel: float sums of its points in input order (the sort is stable).
-__global__ __launch_bounds__(256) void voxel_centroid_kernel(
-    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-    int64_t begin, const unsigned long long* __restrict__ unique_keys,
-    const unsigned int* __restrict__ counts, const unsigned int* __restrict__ offsets,
-    const unsigned int* __restrict__ sorted_idx, unsigned int n_runs, float* __restrict__ out /* AoS xyz */)
+// Coordinates in sorted order (voxel by voxel, input order inside a voxel: the sort is stable),
+// so that the per-voxel sums below read contiguous runs.
+__global__ __launch_bounds__(256) void voxel_gather_kernel(const float* __restrict__ xs,
+                                                           const float* __restrict__ ys,
+                                                           const float* __restrict__ zs, int64_t begin,
+                                                           const unsigned int* __restrict__ sorted_idx, int64_t n,
+                                                           float* __restrict__ gx, float* __restrict__ gy,
+                                                           float* __restrict__ gz)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t i = begin + sorted_idx[t];
+    gx[t] = xs[i];
+    gy[t] = ys[i];
+    gz[t] = zs[i];
+}
+
+// One thread per voxel: float sums of its run in order (one add at a time, as a serial filter
+// does); eight elements are in flight per trip so the loads do not wait for the adds.
+__global__ __launch_bounds__(64) void voxel_centroid_kernel(
+    const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
+    const unsigned int* __restrict__ counts, const unsigned int* __restrict__ offsets, unsigned int n_runs,
+    float* __restrict__ out /* AoS xyz */)
 {
     const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_runs || unique_keys[v] == ~0ull) return;
+    if (v >= n_runs) return;                     // the host passes only the runs of real cells
     const unsigned int o = offsets[v], c = counts[v];
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (unsigned int t = 0; t < c; ++t) {
-        const int64_t i = begin + sorted_idx[o + t];
-        sx += xs[i]; sy += ys[i]; sz += zs[i];
+    unsigned int t = 0;
+    for (; t + 8 <= c; t += 8) {
+        float x[8], y[8], z[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { x[u] = gx[o + t + u]; y[u] = gy[o + t + u]; z[u] = gz[o + t + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sx += x[u]; sy += y[u]; sz += z[u]; }
     }
+    for (; t < c; ++t) { sx += gx[o + t]; sy += gy[o + t]; sz += gz[o + t]; }
     const float cnt = (float)c;
     out[3 * (size_t)v + 0] = sx / cnt;
     out[3 * (size_t)v + 1] = sy / cnt;
@@ -134,64 +157,75 @@ int voxel_downsample_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int
     d.div01 = div[0] * div[1];
     const double cells = (double)div[0] * (double)div[1] * (double)div[2];
     if (!(cells < 9.0e18)) return fail(ctx, CCAL_ERR_ARG, "voxel grid: leaf too small for the cloud extent");
-    int key_bits = 1;
-    while (key_bits < 64 && std::ldexp(1.0, key_bits) <= cells) ++key_bits;
+    d.nonfinite_key = (unsigned long long)div[0] * (unsigned long long)div[1] * (unsigned long long)div[2];
+    unsigned key_bits = 1;
+    while (key_bits < 64 && (1ull << key_bits) <= d.nonfinite_key) ++key_bits;
 
-    // keys, sort, run-length encode
+    // keys, sort, run-length encode (scratch lives in the context and only grows)
     const size_t N = (size_t)n;
-    DevBuf keys, keys2, idx, idx2, uniq, counts, offsets, nruns, tmp;
-    auto rel = [&]() { for (DevBuf* b : {&keys, &keys2, &idx, &idx2, &uniq, &counts, &offsets, &nruns, &tmp}) b->release(); };
-#define VOX_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { rel(); return fail(ctx, CCAL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
-    VOX_HIP(keys.ensure(N * 8)); VOX_HIP(keys2.ensure(N * 8)); VOX_HIP(idx.ensure(N * 4)); VOX_HIP(idx2.ensure(N * 4));
-    VOX_HIP(uniq.ensure(N * 8)); VOX_HIP(counts.ensure(N * 4)); VOX_HIP(offsets.ensure(N * 4)); VOX_HIP(nruns.ensure(4));
+    DevBuf& keys = ctx->vox[0];
+    DevBuf& keys2 = ctx->vox[1];
+    DevBuf& idx = ctx->vox[2];
+    DevBuf& idx2 = ctx->vox[3];
+    DevBuf& uniq = ctx->vox[4];
+    DevBuf& counts = ctx->vox[5];
+    DevBuf& offsets = ctx->vox[6];
+    DevBuf& nruns = ctx->vox[7];
+    DevBuf& tmp = ctx->vox[8];
+    DevBuf& cent = ctx->vox[9];
+    CCAL_HIP(ctx, keys.ensure(N * 8)); CCAL_HIP(ctx, keys2.ensure(N * 8));
+    CCAL_HIP(ctx, idx.ensure(N * 4)); CCAL_HIP(ctx, idx2.ensure(N * 4));
+    CCAL_HIP(ctx, uniq.ensure(N * 8)); CCAL_HIP(ctx, counts.ensure(N * 4));
+    CCAL_HIP(ctx, offsets.ensure(N * 4)); CCAL_HIP(ctx, nruns.ensure(4));
     hipLaunchKernelGGL(voxel_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xs, ys, zs, begin, n, d,
                        keys.as<unsigned long long>(), idx.as<unsigned int>());
-    // non-finite keys are all ones: sort every bit when any may be present
-    const unsigned end_bit = 64;
-    (void)key_bits;
+    // keys are below 2^key_bits (the non-finite key included): only those bits are sorted
     size_t tmp_bytes = 0;
-    VOX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
-                                      idx.as<unsigned int>(), idx2.as<unsigned int>(), N, 0, end_bit, st));
-    VOX_HIP(tmp.ensure(tmp_bytes));
-    VOX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(),
-                                      idx.as<unsigned int>(), idx2.as<unsigned int>(), N, 0, end_bit, st));
+    CCAL_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(),
+                                            keys2.as<unsigned long long>(), idx.as<unsigned int>(),
+                                            idx2.as<unsigned int>(), N, 0, key_bits, st));
+    CCAL_HIP(ctx, tmp.ensure(tmp_bytes));
+    CCAL_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(),
+                                            keys2.as<unsigned long long>(), idx.as<unsigned int>(),
+                                            idx2.as<unsigned int>(), N, 0, key_bits, st));
     size_t tmp2 = 0;
-    VOX_HIP(rocprim::run_length_encode(nullptr, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
-                                       uniq.as<unsigned long long>(), counts.as<unsigned int>(),
-                                       nruns.as<unsigned int>(), st));
-    VOX_HIP(tmp.ensure(tmp2));
-    VOX_HIP(rocprim::run_length_encode(tmp.p, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
-                                       uniq.as<unsigned long long>(), counts.as<unsigned int>(),
-                                       nruns.as<unsigned int>(), st));
+    CCAL_HIP(ctx, rocprim::run_length_encode(nullptr, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
+                                             uniq.as<unsigned long long>(), counts.as<unsigned int>(),
+                                             nruns.as<unsigned int>(), st));
+    CCAL_HIP(ctx, tmp.ensure(tmp2));
+    CCAL_HIP(ctx, rocprim::run_length_encode(tmp.p, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
+                                             uniq.as<unsigned long long>(), counts.as<unsigned int>(),
+                                             nruns.as<unsigned int>(), st));
     unsigned int n_runs = 0;
-    VOX_HIP(hipMemcpyAsync(&n_runs, nruns.p, 4, hipMemcpyDeviceToHost, st));
-    VOX_HIP(hipStreamSynchronize(st));
+    CCAL_HIP(ctx, hipMemcpyAsync(&n_runs, nruns.p, 4, hipMemcpyDeviceToHost, st));
+    CCAL_HIP(ctx, hipStreamSynchronize(st));
     size_t tmp3 = 0;
-    VOX_HIP(rocprim::exclusive_scan(nullptr, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u, n_runs,
-                                    rocprim::plus<unsigned int>(), st));
-    VOX_HIP(tmp.ensure(tmp3));
-    VOX_HIP(rocprim::exclusive_scan(tmp.p, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u, n_runs,
-                                    rocprim::plus<unsigned int>(), st));
-    // the all-ones run (non-finite points), if any, is the last one
+    CCAL_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u,
+                                          n_runs, rocprim::plus<unsigned int>(), st));
+    CCAL_HIP(ctx, tmp.ensure(tmp3));
+    CCAL_HIP(ctx, rocprim::exclusive_scan(tmp.p, tmp3, counts.as<unsigned int>(), offsets.as<unsigned int>(), 0u,
+                                          n_runs, rocprim::plus<unsigned int>(), st));
+    // the run of non-finite points, if any, is the last one
     unsigned long long last_key = 0;
-    VOX_HIP(hipMemcpyAsync(&last_key, uniq.as<unsigned long long>() + (n_runs - 1), 8, hipMemcpyDeviceToHost, st));
-    VOX_HIP(hipStreamSynchronize(st));
-    const unsigned int n_vox = last_key == ~0ull ? n_runs - 1 : n_runs;
-    DevBuf cent;
-    VOX_HIP(cent.ensure((size_t)std::max(1u, n_vox) * 3 * sizeof(float)));
+    CCAL_HIP(ctx, hipMemcpyAsync(&last_key, uniq.as<unsigned long long>() + (n_runs - 1), 8, hipMemcpyDeviceToHost, st));
+    CCAL_HIP(ctx, hipStreamSynchronize(st));
+    const unsigned int n_vox = last_key == d.nonfinite_key ? n_runs - 1 : n_runs;
+    CCAL_HIP(ctx, cent.ensure((size_t)std::max(1u, n_vox) * 3 * sizeof(float)));
     if (n_vox) {
-        hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_vox + 255) / 256), dim3(256), 0, st, xs, ys, zs, begin,
-                           uniq.as<unsigned long long>(), counts.as<unsigned int>(), offsets.as<unsigned int>(),
-                           idx2.as<unsigned int>(), n_vox, cent.as<float>());
+        // keys/keys2 are free after the run-length encode: they hold the gathered coordinates
+        float* gx = keys.as<float>();
+        float* gy = gx + N;
+        float* gz = keys2.as<float>();
+        hipLaunchKernelGGL(voxel_gather_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xs, ys, zs, begin,
+                           idx2.as<unsigned int>(), n, gx, gy, gz);
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_vox + 63) / 64), dim3(64), 0, st, gx, gy, gz,
+                           counts.as<unsigned int>(), offsets.as<unsigned int>(), n_vox, cent.as<float>());
+        CCAL_HIP(ctx, hipGetLastError());
         const size_t o = out.size();
         out.resize(o + (size_t)n_vox * 3);
-        hipError_t e = hipMemcpyAsync(out.data() + o, cent.p, (size_t)n_vox * 3 * sizeof(float), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { cent.release(); rel(); return fail(ctx, CCAL_ERR_DEVICE, hipGetErrorString(e)); }
+        CCAL_HIP(ctx, hipMemcpyAsync(out.data() + o, cent.p, (size_t)n_vox * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        CCAL_HIP(ctx, hipStreamSynchronize(st));
     }
-    cent.release();
-    rel();
-#undef VOX_HIP
     return CCAL_OK;
 }
 
