@@ -899,7 +899,11 @@ static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_p
     const int64_t n_local = end - begin;
     *kernel_ms = 0.0;
     *launches = 0;
-    if (ctx->search_mode == CCAL_SEARCH_SEPARABLE) {
+    // the separable pass keeps 2^-32 m fixed-point sums of up to 64 m per point in 64 bits:
+    // clouds of 2^25 points or more take the dense sweep
+    bool separable = ctx->search_mode == CCAL_SEARCH_SEPARABLE;
+    for (size_t n : cs.n_pts) separable = separable && n < ((size_t)1 << 25);
+    if (separable) {
         const int64_t rot_count = (int64_t)g->count[3] * g->count[4] * g->count[5];
         const int64_t t0 = begin / rot_count, t1 = (end + rot_count - 1) / rot_count;
         // the separable pass fills whole translation rows
