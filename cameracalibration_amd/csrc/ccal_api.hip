@@ -316,63 +316,25 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     cs.base_T_flange.assign(base_T_flange, base_T_flange + 16 * (size_t)n_clouds);
     cs.total_pts = total;
 
-    // ---- exact path: SoA + block table --------------------------------------
-    std::vector<float> hx(total), hy(total), hz(total);
+    // ---- tables: block table of the exact path, group offsets of the fast path ----------
     std::vector<BlockDesc> blocks;
     cs.cloud_block_off.assign(n_clouds + 1, 0);
-    {
-        std::vector<size_t> offs(n_clouds, 0);
-        for (int j = 1; j < n_clouds; ++j) offs[j] = offs[j - 1] + n_pts[j - 1];
-        parallel_over(n_clouds, [&](int j) {
-            const float* p = xyz[j];
-            const size_t o = offs[j];
-            for (size_t i = 0; i < n_pts[j]; ++i) {
-                hx[o + i] = p[3 * i + 0];
-                hy[o + i] = p[3 * i + 1];
-                hz[o + i] = p[3 * i + 2];
-            }
-        });
-    }
-    size_t off = 0;
+    std::vector<int64_t> pt_off(n_clouds + 1, 0);
     for (int j = 0; j < n_clouds; ++j) {
         cs.cloud_block_off[j] = (int)blocks.size();
         for (size_t b = 0; b < n_pts[j]; b += kPointsPerBlock) {
             BlockDesc bd;
             bd.cloud = j;
             bd.first_of_cloud = cs.cloud_block_off[j];
-            bd.begin = (int64_t)(off + b);
-            bd.end = (int64_t)(off + std::min(n_pts[j], b + (size_t)kPointsPerBlock));
+            bd.begin = pt_off[j] + (int64_t)b;
+            bd.end = pt_off[j] + (int64_t)std::min(n_pts[j], b + (size_t)kPointsPerBlock);
             blocks.push_back(bd);
         }
-        off += n_pts[j];
+        pt_off[j + 1] = pt_off[j] + (int64_t)n_pts[j];
     }
     cs.cloud_block_off[n_clouds] = (int)blocks.size();
     cs.n_blocks = (int)blocks.size();
 
-    CCAL_HIP(ctx, cs.xs.ensure(total * sizeof(float)));
-    CCAL_HIP(ctx, cs.ys.ensure(total * sizeof(float)));
-    CCAL_HIP(ctx, cs.zs.ensure(total * sizeof(float)));
-    CCAL_HIP(ctx, cs.blocks.ensure(blocks.size() * sizeof(BlockDesc)));
-    CCAL_HIP(ctx, cs.cloud_block_off_dev.ensure((n_clouds + 1) * sizeof(int)));
-    CCAL_HIP(ctx, hipMemcpy(cs.xs.p, hx.data(), total * sizeof(float), hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.ys.p, hy.data(), total * sizeof(float), hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.zs.p, hz.data(), total * sizeof(float), hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.blocks.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
-                            hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.cloud_block_off_dev.p, cs.cloud_block_off.data(),
-                            (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
-    {
-        std::vector<int64_t> pt_off(n_clouds + 1, 0);
-        for (int j = 0; j < n_clouds; ++j) pt_off[j + 1] = pt_off[j] + (int64_t)n_pts[j];
-        CCAL_HIP(ctx, cs.cloud_pt_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
-        CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(),
-                                (n_clouds + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    }
-    hx.clear(); hx.shrink_to_fit();
-    hy.clear(); hy.shrink_to_fit();
-    hz.clear(); hz.shrink_to_fit();
-
-    // ---- fast path: centred 64-point groups ---------------------------------
     cs.group_off.assign(n_clouds + 1, 0);
     cs.centres.assign(3 * (size_t)n_clouds, 0.0);
     int64_t n_groups = 0;
@@ -388,7 +350,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     cs.n_groups = n_groups;
     cs.n_pad_points = n_groups * kGroupPoints - (int64_t)total;
 
-    std::vector<float> hg((size_t)n_groups * 256, 0.0f);
+    // ---- host: centre of every cloud (FP64 sum in point order) and its weight --------------
     std::vector<double> scale(n_clouds);
     parallel_over(n_clouds, [&](int j) {
         const float* p = xyz[j];
@@ -403,25 +365,44 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             cs.centres[3 * j + k] = c[k];
         }
         scale[j] = 1.0 / ((double)n_clouds * (double)n);
-        float* base = hg.data() + (size_t)cs.group_off[j] * 256;
-        for (size_t i = 0; i < n; ++i) {
-            const size_t g = i / kGroupPoints;
-            const int in_group = (int)(i % kGroupPoints);
-            const int u = in_group / kTilePoints, col = in_group % kTilePoints;
-            float* gp = base + g * 256;
-            // lane l = k*16 + col holds coordinate k; component u selects the tile
-            gp[(0 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 0] - c[0]);
-            gp[(1 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 1] - c[1]);
-            gp[(2 * 16 + col) * 4 + u] = (float)((double)p[3 * i + 2] - c[2]);
-            gp[(3 * 16 + col) * 4 + u] = 1.0f;
-        }
     });
-    CCAL_HIP(ctx, cs.groups.ensure(hg.size() * sizeof(float)));
+
+    // ---- device: one copy of the caller's AoS clouds, both layouts written from it ----------
+    CCAL_HIP(ctx, cs.xs.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.ys.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.zs.ensure(total * sizeof(float)));
+    CCAL_HIP(ctx, cs.groups.ensure((size_t)n_groups * 256 * sizeof(float)));
+    CCAL_HIP(ctx, hipMemsetAsync(cs.groups.p, 0, (size_t)n_groups * 256 * sizeof(float), ctx->stream));
+    {
+        DevBuf stage;   // the AoS copy lives only for this call
+        hipError_t e = stage.ensure(total * 3 * sizeof(float));
+        for (int j = 0; j < n_clouds && e == hipSuccess; ++j) {
+            float* dst = stage.as<float>() + 3 * (size_t)pt_off[j];
+            e = hipMemcpyAsync(dst, xyz[j], n_pts[j] * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
+                               dst, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j], cs.centres[3 * j],
+                               cs.centres[3 * j + 1], cs.centres[3 * j + 2], cs.xs.as<float>(), cs.ys.as<float>(),
+                               cs.zs.as<float>(), cs.groups.as<float>());
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        stage.release();
+        CCAL_HIP(ctx, e);
+    }
+    CCAL_HIP(ctx, cs.blocks.ensure(blocks.size() * sizeof(BlockDesc)));
+    CCAL_HIP(ctx, cs.cloud_block_off_dev.ensure((n_clouds + 1) * sizeof(int)));
+    CCAL_HIP(ctx, cs.cloud_pt_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
     CCAL_HIP(ctx, cs.group_off_dev.ensure((n_clouds + 1) * sizeof(int)));
     CCAL_HIP(ctx, cs.scale_dev.ensure(n_clouds * sizeof(double)));
     CCAL_HIP(ctx, cs.centres_dev.ensure(3 * n_clouds * sizeof(double)));
     CCAL_HIP(ctx, cs.base_dev.ensure(16 * (size_t)n_clouds * sizeof(double)));
-    CCAL_HIP(ctx, hipMemcpy(cs.groups.p, hg.data(), hg.size() * sizeof(float), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.blocks.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.cloud_block_off_dev.p, cs.cloud_block_off.data(),
+                            (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(), (n_clouds + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice));
     cs.split_ready = false;
     if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)
         if (int rc = ensure_split_groups(ctx, cs)) return rc;

@@ -46,6 +46,36 @@ constexpr int kTilePoints = 16;
 constexpr int kFlushGroups = 32;  // FP32 partial sums are promoted every 128 adds
 
 // ---------------------------------------------------------------------------
+// Upload: device-side re-tiling
+// ---------------------------------------------------------------------------
+// The caller's clouds arrive as AoS xyz (one contiguous copy per cloud); this
+// kernel writes both device layouts from them: the SoA coordinates of the exact
+// path and the centred 64-point groups of the fast path (which must be zero
+// beforehand: padding points stay all zero).  One thread per point.
+__global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict__ aos /* this cloud */,
+                                                         int64_t n, int64_t first_point, int64_t first_group,
+                                                         double cx, double cy, double cz,
+                                                         float* __restrict__ xs, float* __restrict__ ys,
+                                                         float* __restrict__ zs, float* __restrict__ groups)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = aos[3 * i + 0], y = aos[3 * i + 1], z = aos[3 * i + 2];
+    xs[first_point + i] = x;
+    ys[first_point + i] = y;
+    zs[first_point + i] = z;
+    const int64_t g = first_group + i / kGroupPoints;
+    const int in_group = (int)(i % kGroupPoints);
+    const int u = in_group / kTilePoints, col = in_group % kTilePoints;
+    float* gp = groups + g * 256;
+    // lane l = k*16 + col holds coordinate k; component u selects the tile
+    gp[(0 * 16 + col) * 4 + u] = (float)((double)x - cx);
+    gp[(1 * 16 + col) * 4 + u] = (float)((double)y - cy);
+    gp[(2 * 16 + col) * 4 + u] = (float)((double)z - cz);
+    gp[(3 * 16 + col) * 4 + u] = 1.0f;
+}
+
+// ---------------------------------------------------------------------------
 // Candidate sources for the W generator
 // ---------------------------------------------------------------------------
 // Grid: per axis a table of translations (axes 0..2) or of sin/cos pairs
