@@ -614,7 +614,8 @@ extern "C" int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, d
     CCAL_HIP(ctx, ctx->dist_buf.ensure(std::max<size_t>(n, 1) * sizeof(double)));
     CCAL_HIP(ctx, ctx->osum_buf.ensure(sizeof(double)));
     CCAL_HIP(ctx, ctx->omax_buf.ensure(sizeof(double)));
-    CCAL_HIP(ctx, hipMemcpyAsync(ctx->dist_buf.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (n)
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->dist_buf.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64 * kChainWaves), 0, ctx->stream, ctx->dist_buf.as<double>(),
                        (int64_t)n, ctx->osum_buf.as<double>(), ctx->omax_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
@@ -694,6 +695,7 @@ static inline double grid_axis_value(const ccal_grid* g, const double base[6], i
 extern "C" void ccal_grid_pose(const ccal_grid* g, const double base_pose[6], int64_t index,
                                double pose[6])
 {
+    if (!g || !base_pose || !pose || ccal_grid_size(g) <= 0 || index < 0) return;
     int idx[6];
     for (int k = 5; k >= 0; --k) {
         idx[k] = (int)(index % g->count[k]);
@@ -705,6 +707,7 @@ extern "C" void ccal_grid_pose(const ccal_grid* g, const double base_pose[6], in
 extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indices)
 {
     int best = -1;
+    if (!costs || !indices) return best;
     for (int i = 0; i < n; ++i) {
         if (indices[i] < 0) continue;
         if (best < 0 || costs[i] < costs[best] ||
