@@ -722,13 +722,15 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
 // ---------------------------------------------------------------------------
 // Translations per launch (histogram bins in LDS) x rotations per workgroup: 1024 x 2 when one
 // launch holds all translations (37 KB of LDS; 2 rotations measured 10 % faster than 4 or 8);
-// 2048 x 2 for longer lists, which halves the number of passes over the points (73 KB).
-template <int TC, int RB>
+// 2048 x 2 for longer lists, which halves the number of passes over the points (74 KB).
+constexpr int kSepBucketsShort = 8, kSepBucketsLong = 4;   // lookup-table buckets per bin (LDS: 16 KB either way)
+
+template <int TC, int RB, int BPB>
 static void launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr)
 {
-    hipLaunchKernelGGL((separable_hist_kernel<TC, RB>), dim3((nr + RB - 1) / RB, cs.n_clouds),
+    hipLaunchKernelGGL((separable_hist_kernel<TC, RB, BPB>), dim3((nr + RB - 1) / RB, cs.n_clouds),
                        dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
-                       wr, ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(), ctx->sep_tab.as<unsigned>(),
+                       wr, ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(), ctx->sep_tab.as<unsigned short>(),
                        ctx->sep_meta.as<SepMeta>(), cs.scale_dev.as<double>(), cs.n_clouds, nt, nr,
                        ctx->partial_buf.as<double>());
 }
@@ -803,10 +805,11 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 
     const bool long_list = t1 - t0 > 1024;
     const int tc = long_list ? 2048 : 1024, rb = 2;
-    const int M = 2 * tc;
+    const int bpb = long_list ? kSepBucketsLong : kSepBucketsShort;
+    const int M = bpb * tc;
     std::vector<float> sb;
     std::vector<int> perm;
-    std::vector<unsigned> tab;
+    std::vector<unsigned short> tab;
     std::vector<SepMeta> meta(C);
     std::vector<std::pair<float, int>> order;
     Events ev;
@@ -816,7 +819,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
         const int nt = (int)std::min<int64_t>(tc, t1 - ta);
         sb.assign((size_t)C * nt, 0.f);
         perm.assign((size_t)C * nt, 0);
-        tab.assign((size_t)C * M, 0u);
+        tab.assign((size_t)C * (M + 1), 0);
         for (int j = 0; j < C; ++j) {
             order.resize(nt);
             for (int tl = 0; tl < nt; ++tl) {
@@ -830,17 +833,20 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
                 perm[(size_t)j * nt + q] = order[q].second;
             }
             const float bmin = order.front().first, bmax = order.back().first;
-            const double delta = bmax > bmin ? ((double)bmax - (double)bmin) / M : 1.0;
-            meta[j].bmin = bmin;
+            const double range = (double)bmax - (double)bmin;
+            const double delta = range > 1e-30 ? range / M : 1.0;
             meta[j].inv_delta = (float)(1.0 / delta);
-            // rank range [lo, hi] of every bucket: lo = thresholds in lower buckets, hi = lo + its own
-            unsigned* tj = tab.data() + (size_t)j * M;
+            meta[j].offset = (float)(-(double)bmin / delta);
+            // entry m: thresholds in buckets below m (the rank a key of bucket m starts from) and how
+            // many bucket m holds itself (0, 1, 2 = more); [M] = nt
+            unsigned short* tj = tab.data() + (size_t)j * (M + 1);
             int q = 0;
             for (int m = 0; m < M; ++m) {
                 const int lo = q;
                 while (q < nt && separable_bucket(order[q].first, meta[j], M) <= m) ++q;
-                tj[m] = (unsigned)lo | ((unsigned)q << 16);
+                tj[m] = (unsigned short)((unsigned)lo | ((unsigned)std::min(q - lo, 2) << kSepRankBits));
             }
+            tj[M] = (unsigned short)nt;
         }
         // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
         const int64_t budget = (int64_t)1 << 30;
@@ -853,14 +859,14 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
         };
         CCAL_HIP(ctx, up(ctx->sep_sb, sb.data(), sb.size() * sizeof(float)));
         CCAL_HIP(ctx, up(ctx->sep_perm, perm.data(), perm.size() * sizeof(int)));
-        CCAL_HIP(ctx, up(ctx->sep_tab, tab.data(), tab.size() * sizeof(unsigned)));
+        CCAL_HIP(ctx, up(ctx->sep_tab, tab.data(), tab.size() * sizeof(unsigned short)));
         CCAL_HIP(ctx, up(ctx->sep_meta, meta.data(), meta.size() * sizeof(SepMeta)));
         for (int64_t ra = 0; ra < R; ra += nr_max) {
             const int nr = (int)std::min<int64_t>(nr_max, R - ra);
             CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
             CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
-            if (long_list) launch_separable<2048, 2>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
-            else launch_separable<1024, 2>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
+            if (long_list) launch_separable<2048, 2, kSepBucketsLong>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
+            else launch_separable<1024, 2, kSepBucketsShort>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
                                0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);

@@ -893,43 +893,55 @@ __global__ __launch_bounds__(256) void select_band_kernel(const float* __restric
 constexpr int kSepThreads = 512;
 
 struct SepMeta {
-    float bmin;        // lowest threshold of the range
     float inv_delta;   // buckets per metre
+    float offset;      // -(lowest threshold) * inv_delta
 };
 
-// Bucket of a key among n_buckets equal slices of [bmin, bmax]; monotone in the key.  Host
-// (table construction) and device (lookup) evaluate this same float expression.
+// Bucket of a key among n_buckets equal slices of the thresholds' range; monotone in the key
+// (one correctly rounded fma, then a clamp).  Host (table construction) and device (lookup)
+// evaluate this same float expression.
 __host__ __device__ inline int separable_bucket(float key, const SepMeta& mt, int n_buckets)
 {
-    float fb = (key - mt.bmin) * mt.inv_delta;
-    fb = fb < 0.f ? 0.f : (fb > (float)(n_buckets - 1) ? (float)(n_buckets - 1) : fb);
+    float fb = __builtin_fmaf(key, mt.inv_delta, mt.offset);
+    const float top = (float)(n_buckets - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    fb = __builtin_amdgcn_fmed3f(fb, 0.f, top);
+#else
+    fb = fb < 0.f ? 0.f : (fb > top ? top : fb);
+#endif
     return (int)fb;
 }
 
-template <int TC, int RB>
+// Lookup-table entry: rank of the bucket's first threshold in the low 12 bits (at most 2048
+// thresholds per launch), thresholds in the bucket (0, 1, 2 = two or more) above them.
+constexpr unsigned kSepRankBits = 12, kSepRankMask = (1u << kSepRankBits) - 1u;
+
+// BPB = buckets of the lookup table per histogram bin: with several the typical bucket holds no
+// threshold or one, so the rank of a key is the table entry plus one or two comparisons.
+template <int TC, int RB, int BPB>
 __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off,
     const f32x4* __restrict__ wr,            // [rotation][cloud]: w1, w2, w3, a
     const float* __restrict__ sb,            // [cloud][nt]: sorted translation constants
     const int* __restrict__ perm,            // [cloud][nt]: rank -> local translation index
-    const unsigned* __restrict__ tab,        // [cloud][2*TC]: rank range of each bucket, lo | hi << 16
+    const unsigned short* __restrict__ tab,  // [cloud][M + 1]: see kSepRankBits; entry [M] = nt
     const SepMeta* __restrict__ meta,        // [cloud]
     const double* __restrict__ scale,        // [cloud]: 1 / (n_clouds * n_points)
     int n_clouds, int nt, int nr, double* __restrict__ partial /* [cloud][nt][nr] */)
 {
-    constexpr int M = 2 * TC;
+    constexpr int M = BPB * TC;
     constexpr unsigned long long kMagicBits = 0x4138000000000000ull;   // 1.5 * 2^20
     __shared__ unsigned int cnt[RB][TC + 1];
     __shared__ unsigned long long sum[RB][TC + 1];
     __shared__ float sbs[TC];
-    __shared__ unsigned tabs[M];
+    __shared__ unsigned short tabs[M + 2];
     const int j = blockIdx.y;
     const int r0 = blockIdx.x * RB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kWaves = kSepThreads / 64;
 
     for (int i = threadIdx.x; i < nt; i += kSepThreads) sbs[i] = sb[(int64_t)j * nt + i];
-    for (int i = threadIdx.x; i < M; i += kSepThreads) tabs[i] = tab[(int64_t)j * M + i];
+    for (int i = threadIdx.x; i <= M; i += kSepThreads) tabs[i] = tab[(int64_t)j * (M + 1) + i];
     for (int i = threadIdx.x; i < RB * (TC + 1); i += kSepThreads) {
         (&cnt[0][0])[i] = 0u;
         (&sum[0][0])[i] = 0ull;
@@ -941,6 +953,8 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
         w[rb] = wr[(int64_t)r * n_clouds + j];
     }
     const SepMeta mt = meta[j];
+    unsigned c_lo[RB] = {}, c_hi[RB] = {};
+    unsigned long long s_lo[RB] = {}, s_hi[RB] = {};
     __syncthreads();
 
     // points: a wave takes four 64-point groups per trip, a lane the four points of one column
@@ -955,22 +969,44 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float v = __builtin_fmaf(w[rb][0], x4[u], __builtin_fmaf(w[rb][1], y4[u], w[rb][2] * z4[u])) + w[rb][3];
-                v = __builtin_fabsf(v) < 64.f ? v : (v < 0.f ? -64.f : 64.f);   // also tames NaN
+                v = __builtin_amdgcn_fmed3f(v, -64.f, 64.f);   // the sums hold 64 m per point; a NaN turns finite
                 const float key = -v;
-                // k = #{q : sbs[q] < key}: the bucket function is monotone and the table was built
-                // with this very expression, so k lies in the bucket's rank range [lo, hi]
-                const unsigned e = tabs[separable_bucket(key, mt, M)];
-                int lo = (int)(e & 0xffffu), hi = (int)(e >> 16);
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sbs[mid] < key) lo = mid + 1; else hi = mid;
+                // k = #{q : sbs[q] < key}.  The bucket function is monotone and the table was built
+                // with this very expression: every threshold of a lower bucket is below the key, every
+                // threshold of a higher bucket above it, so k is the table entry (thresholds in lower
+                // buckets) plus the thresholds of the key's own bucket that lie below it.  Most buckets
+                // hold none (no further read) or one (one comparison).
+                const int bucket = separable_bucket(key, mt, M);
+                const unsigned e = tabs[bucket];
+                int k = (int)(e & kSepRankMask);
+                if (e > kSepRankMask) {
+                    const bool below = sbs[k] < key;
+                    k += below ? 1 : 0;
+                    if (below && (e >> kSepRankBits) > 1u) {   // a crowded bucket: search the rest of it
+                        int hi = (int)(tabs[bucket + 1] & kSepRankMask);
+                        while (k < hi) {
+                            const int mid = (k + hi) >> 1;
+                            if (sbs[mid] < key) k = mid + 1; else hi = mid;
+                        }
+                    }
                 }
-                const int k = lo;
                 const double dv = (double)v + 1572864.0;   // 1.5 * 2^20: low bits = v * 2^32, rounded
-                atomicAdd(&cnt[rb][k], 1u);
-                atomicAdd(&sum[rb][k], (unsigned long long)__double_as_longlong(dv));
+                const unsigned long long fx = (unsigned long long)__double_as_longlong(dv);
+                // the two outer bins take every point beyond the thresholds (most points, for
+                // rotations far from the optimum): those are kept in registers
+                if (k == 0) { ++c_lo[rb]; s_lo[rb] += fx; }
+                else if (k == nt) { ++c_hi[rb]; s_hi[rb] += fx; }
+                else {
+                    atomicAdd(&cnt[rb][k], 1u);
+                    atomicAdd(&sum[rb][k], fx);
+                }
             }
         }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        if (c_lo[rb]) { atomicAdd(&cnt[rb][0], c_lo[rb]); atomicAdd(&sum[rb][0], s_lo[rb]); }
+        if (c_hi[rb]) { atomicAdd(&cnt[rb][nt], c_hi[rb]); atomicAdd(&sum[rb][nt], s_hi[rb]); }
     }
     __syncthreads();
 
