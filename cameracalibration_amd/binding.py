@@ -141,6 +141,7 @@ SIGNATURES = {
     "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
     "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
+    "ccal_set_gd_screening": (C.c_int, [_CTX, C.c_int]),
     "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
     "ccal_write_config": (C.c_int, [C.c_char_p, C.c_char_p, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
@@ -284,6 +285,11 @@ class Optimizer:
     def set_search_mode(self, mode: int) -> None:
         """0 = dense (every residual on the matrix cores), 1 = separable (one histogram pass per rotation)."""
         self._check(self._lib.ccal_set_search_mode(self._ctx, int(mode)))
+
+    def set_gd_screening(self, on: bool) -> None:
+        """Line-search trials are first scored on the fast path and decided from that score when its
+        error bound leaves no doubt (default on; results are identical either way)."""
+        self._check(self._lib.ccal_set_gd_screening(self._ctx, 1 if on else 0))
 
     def set_plane(self, plane: Sequence[float]) -> None:
         p = np.ascontiguousarray(plane, dtype=np.float32)

@@ -265,6 +265,10 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     for (DevBuf& b : ctx->vox) b.release();
     ctx->exact_in.release();
     ctx->exact_out.release();
+    ctx->screen_in.release();
+    ctx->screen_out.release();
+    ctx->screen_partial.release();
+    ctx->screen_w.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;
@@ -373,6 +377,9 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, cs.zs.ensure(total * sizeof(float)));
     CCAL_HIP(ctx, cs.groups.ensure((size_t)n_groups * 256 * sizeof(float)));
     CCAL_HIP(ctx, hipMemsetAsync(cs.groups.p, 0, (size_t)n_groups * 256 * sizeof(float), ctx->stream));
+    CCAL_HIP(ctx, cs.radius_dev.ensure(n_clouds * sizeof(unsigned int)));
+    CCAL_HIP(ctx, hipMemsetAsync(cs.radius_dev.p, 0, n_clouds * sizeof(unsigned int), ctx->stream));
+    std::vector<unsigned int> radius2_bits(n_clouds, 0u);
     {
         DevBuf stage;   // the AoS copy lives only for this call
         hipError_t e = stage.ensure(total * 3 * sizeof(float));
@@ -383,9 +390,12 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
                                dst, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j], cs.centres[3 * j],
                                cs.centres[3 * j + 1], cs.centres[3 * j + 2], cs.xs.as<float>(), cs.ys.as<float>(),
-                               cs.zs.as<float>(), cs.groups.as<float>());
+                               cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j);
         }
         if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(radius2_bits.data(), cs.radius_dev.p, n_clouds * sizeof(unsigned int),
+                               hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         stage.release();
         CCAL_HIP(ctx, e);
@@ -403,6 +413,13 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                             (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(), (n_clouds + 1) * sizeof(int64_t),
                             hipMemcpyHostToDevice));
+    cs.radius.assign(n_clouds, 0.0);
+    for (int j = 0; j < n_clouds; ++j) {
+        float r2;
+        std::memcpy(&r2, &radius2_bits[j], sizeof r2);
+        // FP32 evaluation of the squared length: a few ulps, covered by the factor
+        cs.radius[j] = std::isfinite(r2) ? std::sqrt((double)r2) * (1.0 + 1e-6) : std::numeric_limits<double>::infinity();
+    }
     cs.split_ready = false;
     if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)
         if (int rc = ensure_split_groups(ctx, cs)) return rc;
@@ -565,6 +582,92 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 {
     return ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean,
                             per_cloud_max);
+}
+
+// Error budget of the screening pass against the exact objective, per cloud and pose, with
+// rho = largest distance of a point from the cloud's centre c, m = |M (c,1)| (the centre carried to the
+// base frame) and w4 = the folded constant (the signed distance of the centre):
+//   exact path:  rounds every transformed coordinate to float (src/helpers.hpp:151): the residual moves by at
+//                most 2^-24 |q| <= 2^-24 (rho + m)                      (Cauchy-Schwarz with the unit normal)
+//   fast path:   w and p - c rounded to float, four roundings in the chain, each on a magnitude of at most
+//                |w||p - c| + |w4| <= rho + |w4|:  6 * 2^-24 (rho + |w4|)
+//   sums:        16 + 6 FP32 adds per partial:  22 * 2^-24 of the cloud's mean residual
+// The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
+constexpr double kScreenSlack = 1.25;
+
+int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
+                      double* cost, double* bound)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost || !bound)))
+        return fail(ctx, CCAL_ERR_ARG, "eval_screen: null argument");
+    if (!planes4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "eval_screen: plane not set");
+    if (n_poses == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+    const double u24 = 0x1p-24;
+    std::vector<double> mats((size_t)C * 12), fixed((size_t)C);
+    const int max_batch = 1024;
+    for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const int nb = std::min(max_batch, n_poses - k0);
+        CCAL_HIP(ctx, ctx->screen_in.ensure((size_t)nb * C * 4 * sizeof(float)));
+        CCAL_HIP(ctx, ctx->screen_out.ensure((size_t)nb * C * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * nb * sizeof(double)));
+        float* w = ctx->screen_in.as<float>();
+        double* sums = ctx->screen_out.as<double>();
+        std::vector<double> budget((size_t)nb * C);
+        for (int k = 0; k < nb; ++k) {
+            const int src = k0 + k;
+            pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data());
+            double pl[4];
+            for (int e = 0; e < 4; ++e) pl[e] = planes4 ? planes4[4 * (size_t)src + e] : (double)ctx->plane[e];
+            const double inv_norm = 1.0 / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+            for (int j = 0; j < C; ++j) {
+                const double* M = mats.data() + 12 * (size_t)j;
+                const double* c = cs.centres.data() + 3 * (size_t)j;
+                double wv[4];
+                fold_plane(M, pl, pl[3], inv_norm, c, wv);
+                for (int e = 0; e < 4; ++e) w[((size_t)k * C + j) * 4 + e] = (float)wv[e];
+                double m2 = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
+                    m2 += q * q;
+                }
+                const double rho = cs.radius[j];
+                budget[(size_t)k * C + j] = u24 * (rho + std::sqrt(m2)) + 6.0 * u24 * (rho + std::fabs(wv[3]));
+            }
+        }
+        // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)
+        CCAL_HIP(ctx, ctx->screen_w.ensure((size_t)nb * C * 4 * sizeof(float)));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->screen_w.p, w, (size_t)nb * C * 4 * sizeof(float), hipMemcpyHostToDevice,
+                                     ctx->stream));
+        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
+                           cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
+                           ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
+        hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 255) / 256), dim3(256), 0, ctx->stream,
+                           ctx->screen_partial.as<double>(), cs.cloud_block_off_dev.as<int>(), nb, C, sums);
+        CCAL_HIP(ctx, hipGetLastError());
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < nb; ++k) {
+            double f = 0.0, b = 0.0;
+            for (int j = 0; j < C; ++j) {
+                const double mean = sums[(size_t)k * C + j] / (double)cs.n_pts[j];
+                f += mean;
+                b += budget[(size_t)k * C + j] + 22.0 * u24 * mean;
+            }
+            cost[k0 + k] = f / (double)C;
+            bound[k0 + k] = kScreenSlack * b / (double)C;
+        }
+    }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_gd_screening(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    ctx->gd_screening = on != 0;
+    return CCAL_OK;
 }
 
 extern "C" int ccal_point_errors(ccal_ctx* ctx, int which, const double pose[6], const double* plane4,
@@ -779,8 +882,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             cn[k].resize(g->count[3 + k]);
             for (int i = 0; i < g->count[3 + k]; ++i) {
                 const double a = grid_axis_value(g, base, 3 + k, i);
-                sn[k][i] = std::sin(a);
-                cn[k][i] = std::cos(a);
+                sin_cos(a, &sn[k][i], &cn[k][i]);
             }
         }
         for (int64_t r = 0; r < R; ++r) {
@@ -921,8 +1023,7 @@ static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_p
             gt.cs[k] = dbase + o + g->count[3 + k];
             for (int i = 0; i < g->count[3 + k]; ++i) {
                 const double a = grid_axis_value(g, base_pose, 3 + k, i);
-                tbl[o + i] = std::sin(a);
-                tbl[o + g->count[3 + k] + i] = std::cos(a);
+                sin_cos(a, &tbl[o + i], &tbl[o + g->count[3 + k] + i]);
             }
             o += 2 * (size_t)g->count[3 + k];
         }

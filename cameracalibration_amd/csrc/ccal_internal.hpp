@@ -77,6 +77,8 @@ struct CloudSet {
     bool split_ready = false;          // built on first selection of that kernel
     std::vector<int> group_off;        // n_clouds + 1
     std::vector<double> centres;       // n_clouds * 3
+    DevBuf radius_dev;                 // per cloud: bits of the largest squared distance from the centre
+    std::vector<double> radius;        // per cloud: that distance (infinity if a point is not finite)
     int64_t n_groups = 0;
     int64_t n_pad_points = 0;          // zero points added to fill the last groups
     int min_groups = 0;
@@ -85,7 +87,7 @@ struct CloudSet {
     {
         xs.release(); ys.release(); zs.release(); blocks.release();
         cloud_block_off_dev.release(); cloud_pt_off_dev.release(); groups.release(); group_off_dev.release();
-        scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release();
+        scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release(); radius_dev.release();
         ready = false;
     }
 };
@@ -108,6 +110,9 @@ struct ccal_ctx {
     ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
     ccal::DevBuf vox[10];                // scratch of the device voxel grid
     ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
+    ccal::HostBuf screen_in, screen_out; // four-vectors and per-(pose, cloud) sums of the screening pass
+    ccal::DevBuf screen_partial, screen_w;
+    bool gd_screening = true;            // line-search trials are first screened on the fast path
     ccal::DevBuf mats_buf, planes_buf, psum_buf, osum_buf, omax_buf, tbl_buf, dist_buf;
 };
 
@@ -116,5 +121,11 @@ namespace ccal {
 // Host-side helpers implemented in ccal_api.hip and used by gd.cpp / ransac.
 int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
                double* cost, double* per_cloud_mean, double* per_cloud_max);
+
+// Folded FP32 objective of n poses (planes4: per-pose planes, or null for the context's plane)
+// with a bound on its distance from eval_exact's value: |cost[i] - exact cost of pose i| <=
+// bound[i] whenever both are finite (bound[i] is infinite if the set holds a non-finite point).
+int eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
+                double* cost, double* bound);
 
 } // namespace ccal

@@ -26,11 +26,18 @@
 //     centre has passed Armijo; the main stencil of the next iteration rides
 //     along with them, computed as if the curvature test passes (it is dropped
 //     if it does not).
+//   * most backtracking trials fail the Armijo test by a wide margin, and a few pass it by one:
+//     the centres of a line search are first scored by the folded FP32 pass, which comes with a
+//     bound on its distance from the exact objective (ccal::eval_screen).  A trial whose FP32
+//     value minus the bound is above the Armijo threshold fails whatever its exact value, one
+//     whose FP32 value plus the bound is below it passes; only the trials in between are
+//     evaluated exactly.  The decisions, and so the iterates, are those of the exact values.
 // Values past the accepted trial are dropped.  The evaluation count reported is
 // that of the sequential algorithm (1 + 2*dim per trial it visits).
 #include "ccal_internal.hpp"
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,7 +61,13 @@ struct Machine {
     int ls_it = 0;
     // TRIAL_F: objective values at the centres of the next trials (Armijo needs nothing else);
     // TRIAL_G: the +-eps/2 points of the one trial that passed Armijo (curvature test)
-    enum Phase { MAIN, TRIAL_F, TRIAL_G, DONE } phase = DONE;
+    // SCREEN:  FP32 values and bounds at the centres of the next trials (settles the clear cases)
+    // TRIAL_FG: the centres of the undecided trials up to the one the FP32 values expect to pass,
+    //          with that trial's +-eps/2 points (and the next main stencil) in the same request
+    enum Phase { MAIN, SCREEN, TRIAL_F, TRIAL_FG, TRIAL_G, DONE } phase = DONE;
+    bool screening = false;
+    int fg_trials = 0;         // TRIAL_FG: centres in the request; the last one is the expected pass
+    int64_t n_screen_requests = 0, n_screened_fail = 0, n_screened_pass = 0, n_expected_hits = 0, n_expected_misses = 0;
     // speculation: trials per request (first request of a line search / later ones)
     int last_trials = 3;
     bool first_request = true;
@@ -91,11 +104,29 @@ struct Machine {
         return n;
     }
 
-    // the main stencil of the next iteration, should the trial at xn be accepted
-    void next_main_point(double* xs) const
+    // trials whose centres the next SCREEN request scores (>= 1): the pass costs little more for a
+    // few dozen poses than for one
+    int planned_screen() const
+    {
+        int want = last_trials + 8;
+        if (!first_request) want = 16;
+        if (want > kMaxSpeculated) want = kMaxSpeculated;
+        int n = 1;
+        double a = alpha;
+        int lit = ls_it + 1;
+        while (n < want && (o.wolfe_max_it <= 0 || lit < o.wolfe_max_it) && a * o.wolfe_decrease >= o.wolfe_min_step) {
+            a = o.wolfe_decrease * a;
+            ++lit;
+            ++n;
+        }
+        return n;
+    }
+
+    // the main stencil of the next iteration, should the trial with step length a be accepted
+    void next_main_point(double a, double* xs) const
     {
         for (int k = 0; k < D; ++k) {
-            const double st = o.momentum * step[k] + (1 - o.momentum) * alpha * grad[k];
+            const double st = o.momentum * step[k] + (1 - o.momentum) * a * grad[k];
             xs[k] = x[k] - st;
         }
     }
@@ -104,6 +135,8 @@ struct Machine {
     {
         if (phase == MAIN) return stencil();
         if (phase == TRIAL_G) return 2 * D + (ride_along ? stencil() : 0);
+        if (phase == TRIAL_FG) return fg_trials + 2 * D + (ride_along ? stencil() : 0);
+        if (phase == SCREEN) return planned_screen();
         return planned_trials();
     }
 
@@ -160,17 +193,27 @@ struct Machine {
             double xs[10];
             emit_axis_points(xn, out);
             if (!ride_along) return;
-            next_main_point(xs);
+            next_main_point(alpha, xs);
             std::memcpy(out + (size_t)2 * D * D, xs, sizeof(double) * D);
             emit_axis_points(xs, out + (size_t)(2 * D + 1) * D);
             return;
         }
-        const int n = planned_trials();
+        const int n = phase == SCREEN ? planned_screen() : (phase == TRIAL_FG ? fg_trials : planned_trials());
         double a = alpha, c[10];
         for (int t = 0; t < n; ++t) {
             if (t > 0) a = o.wolfe_decrease * a;   // same recurrence as next_trial()
             for (int k = 0; k < D; ++k) c[k] = x[k] - a * grad[k];
             std::memcpy(out + (size_t)t * D, c, sizeof(double) * D);
+        }
+        if (phase == TRIAL_FG) {
+            // c and a are those of the last centre, the trial expected to pass
+            double xs[10];
+            double* rest = out + (size_t)n * D;
+            emit_axis_points(c, rest);
+            if (!ride_along) return;
+            next_main_point(a, xs);
+            std::memcpy(rest + (size_t)2 * D * D, xs, sizeof(double) * D);
+            emit_axis_points(xs, rest + (size_t)(2 * D + 1) * D);
         }
     }
 
@@ -239,8 +282,78 @@ struct Machine {
         ls_it = 0;
         first_request = true;
         ride_along = true;
-        if (trial_allowed()) next_trial();
-        else finish_iteration();
+        if (trial_allowed()) {
+            next_trial();
+            if (screening) phase = SCREEN;
+        } else {
+            finish_iteration();
+        }
+    }
+
+    // The trial at xn has failed the Armijo test: count it and move to the next one.  Returns false
+    // if the line search (and with it the iteration) ended instead.
+    bool fail_trial()
+    {
+        ++ls_it;
+        ++n_trials;
+        ++n_armijo_fail;
+        n_evals += stencil();
+        if (!trial_allowed()) { finish_iteration(); return false; }
+        next_trial();
+        return true;
+    }
+
+    // fast[t], bound[t]: FP32 objective at the centre of the t-th next trial and a bound on its
+    // distance from the exact value (request_points() of them, in emit() order).
+    void feed_screen(const double* fast, const double* bound)
+    {
+        const int n = planned_screen();
+        ++n_screen_requests;
+        first_request = false;
+        int t = 0;
+        for (; t < n; ++t) {
+            const double thr = fval - o.wolfe_c1 * alpha * gg;
+            const bool sure_fail = std::isfinite(fast[t]) && std::isfinite(bound[t]) && fast[t] - bound[t] > thr;
+            if (!sure_fail) break;
+            ++n_screened_fail;
+            if (!fail_trial()) return;          // the iteration ended: phase is MAIN or DONE
+        }
+        if (t == n) { phase = SCREEN; return; } // all of them failed for sure: screen the next ones
+        // The trial at xn is number t of this request.  If it passes for sure, only its gradient is
+        // wanted.  Otherwise the FP32 values (far closer to the exact ones than their bound) say
+        // which trial to expect to pass: the undecided centres up to it are evaluated exactly
+        // together with its gradient points.
+        const double thr_t = fval - o.wolfe_c1 * alpha * gg;
+        if (std::isfinite(fast[t]) && std::isfinite(bound[t]) && fast[t] + bound[t] <= thr_t) {
+            ++n_screened_pass;
+            phase = TRIAL_G;                    // xn passes Armijo whatever its exact value
+            return;
+        }
+        double a = alpha;
+        for (int u = t; u < n; ++u) {
+            if (std::isfinite(fast[u]) && fast[u] <= fval - o.wolfe_c1 * a * gg) {
+                fg_trials = u - t + 1;
+                phase = TRIAL_FG;
+                return;
+            }
+            a = o.wolfe_decrease * a;
+        }
+        phase = TRIAL_F;                        // no pass in sight: exact centres, as without screening
+    }
+
+    // The trial at xn passed Armijo; fg: objective at its 2*D axis points, then (if it rode along)
+    // at the next main stencil.
+    void feed_gradient(const double* fg)
+    {
+        double g[10], xs[10];
+        next_main_point(alpha, xs);
+        gradient_of(fg, g);
+        first_request = false;
+        const bool rode = ride_along;
+        if (conclude_trial(g) && rode && phase == MAIN && std::memcmp(xs, x, sizeof(double) * D) == 0) {
+            ++n_main_hits;
+            feed_main(fg + 2 * D);   // the stencil that rode along is the one now due
+        }
     }
 
     // f holds request_points() objective values in emit() order.  Every trial the sequential
@@ -248,20 +361,28 @@ struct Machine {
     // not its gradient was needed here: a trial that fails Armijo is rejected whatever its gradient.
     void feed(const double* f)
     {
-        double g[10];
         n_requested += request_points();
         ++n_requests;
         if (phase == MAIN) {
             feed_main(f);
         } else if (phase == TRIAL_G) {
-            double xs[10];
-            next_main_point(xs);
-            gradient_of(f, g);
+            feed_gradient(f);
+        } else if (phase == TRIAL_FG) {
+            const int n = fg_trials;
             first_request = false;
-            const bool rode = ride_along;
-            if (conclude_trial(g) && rode && phase == MAIN && std::memcmp(xs, x, sizeof(double) * D) == 0) {
-                ++n_main_hits;
-                feed_main(f + 2 * D);   // the stencil that rode along is the one now due
+            for (int t = 0; t < n; ++t) {
+                const bool armijo = f[t] <= fval - o.wolfe_c1 * alpha * gg;
+                if (t + 1 < n) {
+                    // an earlier trial than expected passes: its gradient is still to be evaluated
+                    if (armijo) { ++n_expected_misses; phase = TRIAL_G; return; }
+                    if (!fail_trial()) return;
+                } else if (armijo) {
+                    ++n_expected_hits;
+                    feed_gradient(f + n);
+                } else {
+                    ++n_expected_misses;
+                    if (fail_trial() && screening) phase = SCREEN;
+                }
             }
         } else if (phase == TRIAL_F) {
             const int n = planned_trials();
@@ -269,12 +390,7 @@ struct Machine {
             for (int t = 0; t < n; ++t) {
                 const bool armijo = f[t] <= fval - o.wolfe_c1 * alpha * gg;
                 if (armijo) { phase = TRIAL_G; return; }   // xn is this trial's point
-                ++ls_it;
-                ++n_trials;
-                ++n_armijo_fail;
-                n_evals += stencil();
-                if (!trial_allowed()) { finish_iteration(); return; }
-                next_trial();
+                if (!fail_trial()) return;
             }
         }
     }
@@ -332,54 +448,84 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
     }
 
     std::vector<Machine> ms(n_starts);
-    for (int s = 0; s < n_starts; ++s) ms[s].start(dim, x0 + (size_t)s * dim, o);
+    for (int s = 0; s < n_starts; ++s) {
+        ms[s].screening = ctx->gd_screening;
+        ms[s].start(dim, x0 + (size_t)s * dim, o);
+    }
     if (n_starts == 1) {
         ms[0].chains_per_pose = ctx->sets[which].n_clouds;
         ms[0].round_chains = ctx->n_cu;
     }
 
-    std::vector<double> pts, poses, planes, f;
+    // One round: the descents that want exact values share one call, those that want the screening
+    // pass share another; every descent is fed what it asked for and moves on.
+    std::vector<double> pts, poses, planes, f, bound;
     std::vector<int> active;
     std::vector<size_t> offs;
-    for (;;) {
+    auto gather = [&](bool screen) {
         active.clear();
         offs.clear();
         size_t n = 0;
         for (int s = 0; s < n_starts; ++s)
-            if (ms[s].phase != Machine::DONE) {
+            if (ms[s].phase != Machine::DONE && (ms[s].phase == Machine::SCREEN) == screen) {
                 active.push_back(s);
                 offs.push_back(n);
                 n += (size_t)ms[s].request_points();
             }
-        if (active.empty()) break;
+        if (active.empty()) return (size_t)0;
         pts.resize(n * dim);
         for (size_t a = 0; a < active.size(); ++a) ms[active[a]].emit(pts.data() + offs[a] * dim);
         poses.resize(n * 6);
         f.resize(n);
-        const double* planes_ptr = nullptr;
         if (dim == 10) {
             planes.resize(n * 4);
             for (size_t i = 0; i < n; ++i) {
                 std::memcpy(&poses[i * 6], &pts[i * 10], 6 * sizeof(double));
                 std::memcpy(&planes[i * 4], &pts[i * 10 + 6], 4 * sizeof(double));
             }
-            planes_ptr = planes.data();
         } else {
             std::memcpy(poses.data(), pts.data(), n * 6 * sizeof(double));
         }
-        int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), planes_ptr, f.data(), nullptr,
-                                  nullptr);
-        if (rc != CCAL_OK) return rc;
-        for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
+        return n;
+    };
+    double t_screen = 0.0, t_exact = 0.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    for (;;) {
+        bool any = false;
+        if (const size_t n = gather(true)) {
+            any = true;
+            bound.resize(n);
+            const double t0 = now();
+            int rc = ccal::eval_screen(ctx, which, (int)n, poses.data(), dim == 10 ? planes.data() : nullptr, f.data(),
+                                       bound.data());
+            t_screen += now() - t0;
+            if (rc != CCAL_OK) return rc;
+            for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed_screen(f.data() + offs[a], bound.data() + offs[a]);
+        }
+        if (const size_t n = gather(false)) {
+            any = true;
+            const double t0 = now();
+            int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), dim == 10 ? planes.data() : nullptr, f.data(),
+                                      nullptr, nullptr);
+            t_exact += now() - t0;
+            if (rc != CCAL_OK) return rc;
+            for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
+        }
+        if (!any) break;
     }
+    if (std::getenv("CCAL_GD_STATS"))
+        std::fprintf(stderr, "gd: %.3f s in screening calls, %.3f s in exact calls\n", t_screen, t_exact);
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
             std::fprintf(stderr, "gd[%d]: %lld evaluations of the sequential algorithm, %lld evaluated in %lld requests; %lld trials, "
                          "%lld failed Armijo, %lld passed Armijo but failed the curvature test; %lld main "
-                         "stencils rode along with a gradient\n", s,
+                         "stencils rode along with a gradient; %lld screening requests settled %lld failing and "
+                         "%lld passing trials; the expected trial passed %lld times, another %lld times\n", s,
                          (long long)ms[s].n_evals, (long long)ms[s].n_requested, (long long)ms[s].n_requests,
                          (long long)ms[s].n_trials, (long long)ms[s].n_armijo_fail, (long long)ms[s].n_wolfe_only_fail,
-                         (long long)ms[s].n_main_hits);
+                         (long long)ms[s].n_main_hits, (long long)ms[s].n_screen_requests,
+                         (long long)ms[s].n_screened_fail, (long long)ms[s].n_screened_pass,
+                         (long long)ms[s].n_expected_hits, (long long)ms[s].n_expected_misses);
     for (int s = 0; s < n_starts; ++s) ms[s].result(&results[s]);
     return CCAL_OK;
 }

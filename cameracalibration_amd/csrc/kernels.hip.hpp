@@ -56,23 +56,36 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
                                                          int64_t n, int64_t first_point, int64_t first_group,
                                                          double cx, double cy, double cz,
                                                          float* __restrict__ xs, float* __restrict__ ys,
-                                                         float* __restrict__ zs, float* __restrict__ groups)
+                                                         float* __restrict__ zs, float* __restrict__ groups,
+                                                         unsigned int* __restrict__ radius2_bits /* this cloud */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = aos[3 * i + 0], y = aos[3 * i + 1], z = aos[3 * i + 2];
-    xs[first_point + i] = x;
-    ys[first_point + i] = y;
-    zs[first_point + i] = z;
-    const int64_t g = first_group + i / kGroupPoints;
-    const int in_group = (int)(i % kGroupPoints);
-    const int u = in_group / kTilePoints, col = in_group % kTilePoints;
-    float* gp = groups + g * 256;
-    // lane l = k*16 + col holds coordinate k; component u selects the tile
-    gp[(0 * 16 + col) * 4 + u] = (float)((double)x - cx);
-    gp[(1 * 16 + col) * 4 + u] = (float)((double)y - cy);
-    gp[(2 * 16 + col) * 4 + u] = (float)((double)z - cz);
-    gp[(3 * 16 + col) * 4 + u] = 1.0f;
+    float r2 = 0.f;
+    if (i < n) {
+        const float x = aos[3 * i + 0], y = aos[3 * i + 1], z = aos[3 * i + 2];
+        xs[first_point + i] = x;
+        ys[first_point + i] = y;
+        zs[first_point + i] = z;
+        const int64_t g = first_group + i / kGroupPoints;
+        const int in_group = (int)(i % kGroupPoints);
+        const int u = in_group / kTilePoints, col = in_group % kTilePoints;
+        float* gp = groups + g * 256;
+        // lane l = k*16 + col holds coordinate k; component u selects the tile
+        const float dx = (float)((double)x - cx), dy = (float)((double)y - cy), dz = (float)((double)z - cz);
+        gp[(0 * 16 + col) * 4 + u] = dx;
+        gp[(1 * 16 + col) * 4 + u] = dy;
+        gp[(2 * 16 + col) * 4 + u] = dz;
+        gp[(3 * 16 + col) * 4 + u] = 1.0f;
+        r2 = dx * dx + dy * dy + dz * dz;
+    }
+    // largest squared distance from the centre: non-negative floats order like their bit patterns,
+    // and a NaN's pattern lies above infinity's, so a non-finite point leaves a non-finite mark
+    unsigned int bits = __float_as_uint(r2);
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)bits, off, 64);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(radius2_bits, bits);
 }
 
 // ---------------------------------------------------------------------------
@@ -1070,6 +1083,35 @@ __global__ __launch_bounds__(256) void separable_reduce_kernel(const double* __r
 }
 
 // ---------------------------------------------------------------------------
+// Screening pass: the folded FP32 objective of a few poses, one pass over the points
+// ---------------------------------------------------------------------------
+// sum_i |w.(p_i - c, 1)| per (pose, cloud) for up to a few dozen poses at once: every lane keeps
+// 16 points in registers and walks the poses in tiles of kScreenTile (the four-vectors are uniform:
+// scalar loads).  Roundings per residual: four (three fused multiply-adds and a product); per
+// partial sum: 16 FP32 adds in the lane and 6 in the wave reduction; everything after that is
+// FP64 in a fixed order.  The caller turns these counts into an error bound.
+struct BlockDesc;
+constexpr int kScreenTile = 16;
+
+__global__ __launch_bounds__(256) void screen_cost_kernel(
+    const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
+    const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w /* [pose][cloud] */, int n_poses,
+    int n_clouds, double* __restrict__ partial /* [block][pose] */);
+
+// out[pose * n_clouds + cloud] = sum of the cloud's block partials in block order
+__global__ __launch_bounds__(256) void screen_reduce_kernel(const double* __restrict__ partial,
+                                                             const int* __restrict__ cloud_block_off, int n_poses,
+                                                             int n_clouds, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_poses * n_clouds) return;
+    const int p = i / n_clouds, j = i % n_clouds;
+    double s = 0.0;
+    for (int b = cloud_block_off[j]; b < cloud_block_off[j + 1]; ++b) s += partial[(int64_t)b * n_poses + p];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------
 // Exact path
 // ---------------------------------------------------------------------------
 // A block covers a contiguous run of points of one cloud.
@@ -1079,6 +1121,64 @@ struct BlockDesc {
     int64_t begin;
     int64_t end;
 };
+
+__global__ __launch_bounds__(256) void screen_cost_kernel(
+    const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
+    const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w, int n_poses, int n_clouds,
+    double* __restrict__ partial)
+{
+    __shared__ float red[4][kScreenTile];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const int j = bd.cloud;
+    // a block of the table is 4096 consecutive points of one cloud = 64 groups
+    const int64_t lb = bd.begin - cloud_pt_off[j], le = bd.end - cloud_pt_off[j];
+    const int g0 = group_off[j] + (int)(lb / kGroupPoints);
+    const int g1 = group_off[j] + (int)((le + kGroupPoints - 1) / kGroupPoints);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, gsel = lane >> 4;
+    f32x4 X[4], Y[4], Z[4], O[4];
+#pragma unroll
+    for (int trip = 0; trip < 4; ++trip) {
+        const int g = g0 + trip * 16 + wave * 4 + gsel;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        X[trip] = Y[trip] = Z[trip] = O[trip] = zero;   // absent groups add |0|
+        if (g < g1) {
+            const f32x4* gp = groups + (int64_t)g * 64 + col;
+            X[trip] = gp[0]; Y[trip] = gp[16]; Z[trip] = gp[32]; O[trip] = gp[48];
+        }
+    }
+    for (int p0 = 0; p0 < n_poses; p0 += kScreenTile) {
+        float acc[kScreenTile];
+#pragma unroll
+        for (int t = 0; t < kScreenTile; ++t) {
+            const int p = p0 + t < n_poses ? p0 + t : n_poses - 1;   // a short last tile repeats its last pose
+            const f32x4 wv = w[(int64_t)p * n_clouds + j];
+            float a = 0.f;
+#pragma unroll
+            for (int trip = 0; trip < 4; ++trip)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float r = __builtin_fmaf(wv[0], X[trip][u], __builtin_fmaf(wv[1], Y[trip][u],
+                                    __builtin_fmaf(wv[2], Z[trip][u], wv[3] * O[trip][u])));
+                    a += __builtin_fabsf(r);
+                }
+            acc[t] = a;
+        }
+#pragma unroll
+        for (int t = 0; t < kScreenTile; ++t) {
+            float a = acc[t];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (lane == 0) red[wave][t] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x < kScreenTile && p0 + (int)threadIdx.x < n_poses) {
+            const int t = threadIdx.x;
+            partial[(int64_t)blockIdx.x * n_poses + p0 + t] =
+                (((double)red[0][t] + (double)red[1][t]) + (double)red[2][t]) + (double)red[3][t];
+        }
+        __syncthreads();
+    }
+}
 
 // Per (pose, cloud): rows 0..2 of M = base_T_flange_j * F(pose), 12 doubles.
 // Per pose: plane a,b,c,d, sqrt(a^2+b^2+c^2), its rounded reciprocal and a flag

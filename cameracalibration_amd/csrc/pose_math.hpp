@@ -24,13 +24,20 @@ struct SinCos3 {
     double c[3];
 };
 
+// Sine and cosine of one angle the way the reference's binary gets them: Eigen's
+// AngleAxis::toRotationMatrix takes sin and cos of the same angle, and gcc merges such a pair into
+// one call of glibc's sincos() at any optimisation level.  sincos() is not bit-identical to
+// sin()/cos(): about one argument in a thousand differs in the last place, so every host-side
+// sine/cosine of this library goes through this one function.
+inline void sin_cos(double angle, double* s, double* c)
+{
+    ::sincos(angle, s, c);
+}
+
 inline SinCos3 sincos_of_pose(const double pose[6])
 {
     SinCos3 sc;
-    for (int k = 0; k < 3; ++k) {
-        sc.s[k] = std::sin(pose[3 + k]);
-        sc.c[k] = std::cos(pose[3 + k]);
-    }
+    for (int k = 0; k < 3; ++k) sin_cos(pose[3 + k], &sc.s[k], &sc.c[k]);
     return sc;
 }
 

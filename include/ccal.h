@@ -243,6 +243,14 @@ int  ccal_gd_minimize(ccal_ctx* ctx, int which, int dim, const double* x0,
 int  ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_starts,
                             const double* x0, const ccal_gd_opts* opts,
                             ccal_gd_result* results);
+/* Line-search screening (on by default; on != 0 enables).  The backtracking trials of
+ * WolfeBacktracking (gdcpp, instantiated at :428 and :486) mostly fail the Armijo test by a wide
+ * margin: their centres are first scored by the FP32 fast path, which comes with a bound on its
+ * distance from the reference-arithmetic value; a trial is decided from that score only when the
+ * bound leaves no doubt, every other trial is evaluated with ccal_eval arithmetic.  Iterates,
+ * counts and values are the same with screening on or off; off evaluates every trial centre
+ * with the reference arithmetic. */
+int  ccal_set_gd_screening(ccal_ctx* ctx, int on);
 
 /* ---- host-side ingest and the whole run -------------------------------------
  * These three do not touch the GPU. */

@@ -9,6 +9,7 @@
  *
  * Citations are relative to the reference tree (src/...).
  */
+#define _GNU_SOURCE /* sincos() */
 #include "ccal_oracle.h"
 
 #include <math.h>
@@ -33,8 +34,12 @@ double orc_degree_to_radian(int angle)
  * (1-c)*1 + c on the axis (not forced to exactly 1). */
 static void axis_rotation(int k, double angle, double R[9])
 {
-    double s = sin(angle);
-    double c = cos(angle);
+    /* Eigen takes sin and cos of the same angle; gcc turns such a pair into one sincos() call at
+     * any optimisation level, and glibc's sincos() differs from sin()/cos() in the last place for
+     * about one argument in a thousand.  Called explicitly so that the result does not hang on
+     * the optimiser. */
+    double s, c;
+    sincos(angle, &s, &c);
     double on_axis = (1.0 - c) * 1.0 + c;
     for (int i = 0; i < 9; ++i) R[i] = 0.0;
     if (k == 2) {            /* Z */

@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle stress run (not collected by pytest; run it by hand on a GPU box):
 
-    python tests/stress_gpu.py [seconds] [seed]
+    python tests/stress_gpu.py [seconds] [seed] [exact|search|gd|ingest]
 
 Draws scenes, poses, planes, grids and optimiser options at random -- sizes around the kernels'
 run/segment/pass boundaries, coordinate scales over many decades, special values -- and checks the
@@ -125,13 +125,31 @@ def check_search(opt, rng, stats):
 
 
 def check_gd(opt, rng, stats):
-    s = make_scene(int(rng.integers(1, 4)), int(rng.choice([60, 400, 2500])), seed=int(rng.integers(1 << 30)),
-                   ragged=bool(rng.integers(2)))
+    wild = rng.random() < 0.25
+    if wild:
+        # arbitrary clouds, robot poses and plane (scales over decades, special values): the error
+        # bound of the line-search screening has to hold there too
+        clouds, B, scale = random_clouds(rng)
+        clouds = [c[:3000] for c in clouds]
+        plane = rng.normal(0, 1, 4).astype(np.float32)
+        plane[3] *= np.float32(scale)
+        if not np.any(plane[:3]):
+            plane[2] = 1
+        pose_init = np.concatenate([rng.normal(0, scale, 3), rng.uniform(-3, 3, 3)])
+
+        class S:
+            pass
+        s = S()
+        s.clouds, s.base_T_flange, s.plane, s.pose_init = clouds, B, plane, pose_init
+    else:
+        s = make_scene(int(rng.integers(1, 4)), int(rng.choice([60, 400, 2500])), seed=int(rng.integers(1 << 30)),
+                       ragged=bool(rng.integers(2)))
     opt.upload_clouds(0, s.clouds, s.base_T_flange)
     opt.set_plane(s.plane)
+    opt.set_gd_screening(bool(rng.random() < 0.85))
     o = O.OracleScene(s.clouds, s.base_T_flange)
     go, oo = cc.GdOptions.default(), O.gd_default_opts()
-    it = int(rng.integers(1, 12))
+    it = int(rng.integers(1, 4 if wild else 12))
     mom = float(rng.choice([0.0, 0.4, 0.9]))
     c2 = float(rng.choice([0.9, 0.2, -1.0]))
     dec = float(rng.choice([0.8, 0.5, 0.3]))
@@ -202,7 +220,11 @@ def check_ingest(opt, rng, stats):
     gd, gc = opt.point_errors(pose, viewer_arithmetic=viewer, which=1)
     if not (same(gd, wd) and np.array_equal(gc, wc)):
         stats["bad"] += 1
-        print("MISMATCH point errors", viewer, s.n_points, flush=True)
+        bad_d = np.flatnonzero(~((gd == wd) | (np.isnan(gd) & np.isnan(wd))))
+        bad_c = np.flatnonzero(gc != wc)
+        print("MISMATCH point errors", viewer, s.n_points, len(bad_d), len(bad_c),
+              [(int(i), float(gd[i]).hex(), float(wd[i]).hex()) for i in bad_d[:3]],
+              [(int(i), int(gc[i]), int(wc[i]), float(gd[i]).hex()) for i in bad_c[:3]], flush=True)
     want = O.fit_plane(o.combined_cloud(pose))
     got = opt.fit_plane(pose, which=1)
     if not np.allclose(got, want, rtol=0, atol=3e-8):
@@ -220,6 +242,7 @@ def check_ingest(opt, rng, stats):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    only = sys.argv[3] if len(sys.argv) > 3 else ""
     rng = np.random.default_rng(seed)
     O.lib()
     opt = cc.Optimizer(0)
@@ -229,7 +252,9 @@ def main():
     np.seterr(all="ignore")
     while time.time() - t0 < seconds:
         u = rng.random()
-        if u < 0.35:
+        if only:
+            {"exact": check_exact, "search": check_search, "gd": check_gd, "ingest": check_ingest}[only](opt, rng, stats)
+        elif u < 0.35:
             check_exact(opt, rng, stats)
         elif u < 0.6:
             check_search(opt, rng, stats)

@@ -46,10 +46,13 @@ def test_grid_pose_and_size_match_oracle(ccal, oracle):
 
 
 def test_pose_matrix_bit_equal_to_oracle(ccal, oracle):
+    """Many poses: glibc's sincos() (what gcc makes of Eigen's sin and cos of one angle) differs from
+    sin()/cos() in the last place for about one angle in a thousand, so a library that took the
+    other route would agree with the oracle on a few hundred poses and differ on the next."""
     rng = np.random.default_rng(2)
-    for _ in range(200):
+    for _ in range(40000):
         pose = rng.normal(0, 1, 6) * np.array([0.5, 0.5, 0.5, 3.0, 1.5, 3.0])
-        np.testing.assert_array_equal(ccal.pose_to_matrix(pose), oracle.pose_to_matrix(pose))
+        assert np.array_equal(ccal.pose_to_matrix(pose), oracle.pose_to_matrix(pose)), pose
 
 
 def test_argmin_merge(ccal):

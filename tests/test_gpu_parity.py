@@ -475,6 +475,33 @@ def test_gradient_descent_line_search_branches(gpu_opt, oracle, tweak):
     assert (r.iterations, r.converged, r.n_evals, r.fval) == (w.iterations, bool(w.converged), w.n_evals, w.fval)
 
 
+def test_gradient_descent_screening_changes_nothing(gpu_opt, oracle):
+    """Line-search trials decided from the fast path's score and its error bound (the default) give the
+    iterates, counts and values of a descent that evaluates every trial centre exactly, in 6-D and 10-D,
+    on a scene large enough for the bound to leave most failing trials no doubt."""
+    import cameracalibration_amd as cc
+    s = make_scene(4, 20000, seed=21, ragged=True)
+    upload(gpu_opt, s)
+    opts = cc.GdOptions.default()
+    opts.max_iterations = 30
+    for x0 in (s.pose_init, np.concatenate([s.pose_init, s.plane.astype(np.float64)])):
+        res = []
+        for on in (True, False):
+            gpu_opt.set_gd_screening(on)
+            res.append(gpu_opt.gradient_descent(x0, opts))
+        gpu_opt.set_gd_screening(True)
+        np.testing.assert_array_equal(res[0].xval, res[1].xval)
+        assert (res[0].iterations, res[0].converged, res[0].n_evals, res[0].fval) == \
+               (res[1].iterations, res[1].converged, res[1].n_evals, res[1].fval)
+    # and both are the oracle's descent
+    oo = oracle.gd_default_opts()
+    oo.max_iterations = 30
+    w = oracle.OracleScene(s.clouds, s.base_T_flange).gd_minimize(s.plane, s.pose_init, oo)
+    r = gpu_opt.gradient_descent(s.pose_init, opts)
+    np.testing.assert_array_equal(r.xval, np.array(w.xval[:6]))
+    assert (r.iterations, r.n_evals, r.fval) == (w.iterations, w.n_evals, w.fval)
+
+
 def test_multi_start_gd_equals_single_starts(gpu_opt):
     s = make_scene(3, 400, seed=8)
     upload(gpu_opt, s)
