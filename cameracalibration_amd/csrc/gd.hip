@@ -16,7 +16,7 @@
 //       step   = momentum*step + (1-momentum)*alpha*g
 //
 // Objective values come from batched calls into the exact objective; several
-// independent descents advance in lock step and share those calls.  Two facts
+// independent descents advance in lock step and share those calls.  Three facts
 // keep the batches small without changing a single iterate:
 //   * the backtracking trials of one line search are known in advance
 //     (alpha = 0.8^k), so the centres of a run of them are evaluated in one pass
@@ -32,6 +32,10 @@
 //     value minus the bound is above the Armijo threshold fails whatever its exact value, one
 //     whose FP32 value plus the bound is below it passes; only the trials in between are
 //     evaluated exactly.  The decisions, and so the iterates, are those of the exact values.
+//     The FP32 values are far closer to the exact ones than their bound, so they also say which
+//     trial to expect to pass: the undecided centres up to it go into one exact request together
+//     with its finite-difference points and the next main stencil (two dependent device steps
+//     per iteration; the speculation is dropped when another trial passes).
 // Values past the accepted trial are dropped.  The evaluation count reported is
 // that of the sequential algorithm (1 + 2*dim per trial it visits).
 #include "ccal_internal.hpp"
