@@ -645,7 +645,7 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
         hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
                            cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
                            ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
-        hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 255) / 256), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 3) / 4), dim3(256), 0, ctx->stream,
                            ctx->screen_partial.as<double>(), cs.cloud_block_off_dev.as<int>(), nb, C, sums);
         CCAL_HIP(ctx, hipGetLastError());
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));

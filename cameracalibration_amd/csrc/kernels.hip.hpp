@@ -80,12 +80,18 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
     }
     // largest squared distance from the centre: non-negative floats order like their bit patterns,
     // and a NaN's pattern lies above infinity's, so a non-finite point leaves a non-finite mark
+    __shared__ unsigned int wave_bits[4];
     unsigned int bits = __float_as_uint(r2);
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned int o = (unsigned int)__shfl_xor((int)bits, off, 64);
         bits = o > bits ? o : bits;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(radius2_bits, bits);
+    if ((threadIdx.x & 63) == 0) wave_bits[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) bits = wave_bits[w] > bits ? wave_bits[w] : bits;
+        atomicMax(radius2_bits, bits);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1098,17 +1104,20 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
     const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w /* [pose][cloud] */, int n_poses,
     int n_clouds, double* __restrict__ partial /* [block][pose] */);
 
-// out[pose * n_clouds + cloud] = sum of the cloud's block partials in block order
+// out[pose * n_clouds + cloud] = sum of the cloud's block partials; one wave per (pose, cloud): lane l adds
+// the partials l, l + 64, ... in order, then the lanes combine in a fixed tree (the same bits on every run).
 __global__ __launch_bounds__(256) void screen_reduce_kernel(const double* __restrict__ partial,
                                                              const int* __restrict__ cloud_block_off, int n_poses,
                                                              int n_clouds, double* __restrict__ out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n_poses * n_clouds) return;
     const int p = i / n_clouds, j = i % n_clouds;
     double s = 0.0;
-    for (int b = cloud_block_off[j]; b < cloud_block_off[j + 1]; ++b) s += partial[(int64_t)b * n_poses + p];
-    out[i] = s;
+    for (int b = cloud_block_off[j] + lane; b < cloud_block_off[j + 1]; b += 64) s += partial[(int64_t)b * n_poses + p];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) out[i] = s;
 }
 
 // ---------------------------------------------------------------------------
