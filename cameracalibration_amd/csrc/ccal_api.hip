@@ -588,9 +588,10 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 // rho = largest distance of a point from the cloud's centre c, m = |M (c,1)| (the centre carried to the
 // base frame) and w4 = the folded constant (the signed distance of the centre):
 //   exact path:  rounds every transformed coordinate to float (src/helpers.hpp:151): the residual moves by at
-//                most 2^-24 |q| <= 2^-24 (rho + m)                      (Cauchy-Schwarz with the unit normal)
+//                most 2^-24 |q| <= 2^-24 (|R|_F rho + m)                (Cauchy-Schwarz with the unit normal;
+//                                                                       R = the 3x3 part of M)
 //   fast path:   w and p - c rounded to float, four roundings in the chain, each on a magnitude of at most
-//                |w||p - c| + |w4| <= rho + |w4|:  6 * 2^-24 (rho + |w4|)
+//                |w123||p - c| + |w4| <= |w123| rho + |w4|:  6 * 2^-24 (|w123| rho + |w4|)
 //   sums:        16 + 6 FP32 adds per partial:  22 * 2^-24 of the cloud's mean residual
 // The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
 constexpr double kScreenSlack = 1.25;
@@ -629,13 +630,17 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
                 double wv[4];
                 fold_plane(M, pl, pl[3], inv_norm, c, wv);
                 for (int e = 0; e < 4; ++e) w[((size_t)k * C + j) * 4 + e] = (float)wv[e];
-                double m2 = 0.0;
+                // |q| <= |R|_F rho + |M (c,1)| for the transformed point, |w123 . (p - c)| <= |w123| rho
+                // (the robot poses are whatever the caller uploaded: no norm is taken for granted)
+                double m2 = 0.0, r2 = 0.0;
                 for (int r = 0; r < 3; ++r) {
                     const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
                     m2 += q * q;
+                    r2 += M[r * 4] * M[r * 4] + M[r * 4 + 1] * M[r * 4 + 1] + M[r * 4 + 2] * M[r * 4 + 2];
                 }
                 const double rho = cs.radius[j];
-                budget[(size_t)k * C + j] = u24 * (rho + std::sqrt(m2)) + 6.0 * u24 * (rho + std::fabs(wv[3]));
+                const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
+                budget[(size_t)k * C + j] = u24 * (std::sqrt(r2) * rho + std::sqrt(m2)) + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
             }
         }
         // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)

@@ -131,6 +131,10 @@ def check_gd(opt, rng, stats):
         # bound of the line-search screening has to hold there too
         clouds, B, scale = random_clouds(rng)
         clouds = [c[:3000] for c in clouds]
+        if rng.random() < 0.4:
+            # robot "poses" that are not rigid: scaled and sheared 3x3 parts
+            B = B.copy()
+            B[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]] *= 10.0 ** rng.uniform(-1, 1, (len(B), 9))
         plane = rng.normal(0, 1, 4).astype(np.float32)
         plane[3] *= np.float32(scale)
         if not np.any(plane[:3]):
