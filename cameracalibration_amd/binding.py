@@ -142,6 +142,7 @@ SIGNATURES = {
     "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_gd_screening": (C.c_int, [_CTX, C.c_int]),
+    "ccal_set_chain_split": (C.c_int, [_CTX, C.c_int]),
     "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
     "ccal_write_config": (C.c_int, [C.c_char_p, C.c_char_p, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
@@ -290,6 +291,11 @@ class Optimizer:
         """Line-search trials are first scored on the fast path and decided from that score when its
         error bound leaves no doubt (default on; results are identical either way)."""
         self._check(self._lib.ccal_set_gd_screening(self._ctx, 1 if on else 0))
+
+    def set_chain_split(self, on: bool) -> None:
+        """A descent's small exact requests cut every (pose, cloud) sum into concurrently folded parts
+        (default on; results are identical either way)."""
+        self._check(self._lib.ccal_set_chain_split(self._ctx, 1 if on else 0))
 
     def set_plane(self, plane: Sequence[float]) -> None:
         p = np.ascontiguousarray(plane, dtype=np.float32)

@@ -269,6 +269,8 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     ctx->screen_out.release();
     ctx->screen_partial.release();
     ctx->screen_w.release();
+    ctx->split_maps.release();
+    ctx->split_first.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;
@@ -338,6 +340,14 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     }
     cs.cloud_block_off[n_clouds] = (int)blocks.size();
     cs.n_blocks = (int)blocks.size();
+    // 512-element segments of every chain (counted from the cloud's start rounded down to a run), one
+    // slot more per cloud for the sum at the chain's end
+    std::vector<int64_t> seg_off(n_clouds + 1, 0);
+    for (int j = 0; j < n_clouds; ++j) {
+        const int64_t b0 = pt_off[j] & ~(int64_t)(kChainRun - 1);
+        seg_off[j + 1] = seg_off[j] + (pt_off[j + 1] - b0 + kChainSeg - 1) / kChainSeg + 1;
+    }
+    cs.total_segs = seg_off[n_clouds];
 
     cs.group_off.assign(n_clouds + 1, 0);
     cs.centres.assign(3 * (size_t)n_clouds, 0.0);
@@ -413,6 +423,11 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                             (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(), (n_clouds + 1) * sizeof(int64_t),
                             hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, cs.cloud_seg_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
+    CCAL_HIP(ctx, hipMemcpy(cs.cloud_seg_off_dev.p, seg_off.data(), (n_clouds + 1) * sizeof(int64_t),
+                            hipMemcpyHostToDevice));
+    CCAL_HIP(ctx, cs.seg_sums.ensure((size_t)cs.total_segs * sizeof(double)));
+    CCAL_HIP(ctx, hipMemset(cs.seg_sums.p, 0, (size_t)cs.total_segs * sizeof(double)));
     cs.radius.assign(n_clouds, 0.0);
     for (int j = 0; j < n_clouds; ++j) {
         float r2;
@@ -519,7 +534,7 @@ static void launch_exact_chains(ccal_ctx* ctx, const CloudSet& cs, int n_poses, 
 
 int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
                      const double* planes4, double* cost, double* per_cloud_mean,
-                     double* per_cloud_max)
+                     double* per_cloud_max, bool allow_split)
 {
     if (int rc = check_set(ctx, which)) return rc;
     if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost)))
@@ -559,9 +574,33 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
             pl[6] = (pl[4] > 0x1p-300 && pl[4] < 0x1p300) ? 1.0 : 0.0;
             pl[7] = 0.0;
         }
-        launch_exact_chains(ctx, cs, nb, per_cloud_max != nullptr, ExactTables{mats, planes, hsum, hmax});
+        // Requests too small to fill the chip with whole chains cut every chain into K parts (see
+        // split_chain_kernel); hmax's slots then carry the number of segments summed twice.
+        const int64_t chains = (int64_t)nb * C;
+        const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu;
+        if (split) {
+            const int K = chains >= ctx->n_cu ? 4 : (chains * 4 >= ctx->n_cu ? 8 : 16);
+            CCAL_HIP(ctx, ctx->split_maps.ensure((size_t)nb * cs.total_segs * sizeof(SegMap)));
+            CCAL_HIP(ctx, ctx->split_first.ensure(n_out * sizeof(double)));
+            hipLaunchKernelGGL(split_chain_kernel, dim3((unsigned)(chains * K)), dim3(64 * kSplitWaves), 0, ctx->stream,
+                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
+                               cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
+                               cs.seg_sums.as<double>(), cs.total_segs, ctx->split_maps.as<SegMap>(),
+                               ctx->split_first.as<double>());
+            hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)chains), dim3(64), 0, ctx->stream, cs.xs.as<float>(),
+                               cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
+                               cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
+                               ctx->split_maps.as<SegMap>(), cs.total_segs, ctx->split_first.as<double>(),
+                               cs.seg_sums.as<double>(), hsum, hmax);
+        } else {
+            launch_exact_chains(ctx, cs, nb, per_cloud_max != nullptr, ExactTables{mats, planes, hsum, hmax});
+        }
         CCAL_HIP(ctx, hipGetLastError());
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (split) {
+            for (size_t i = 0; i < n_out; ++i) ctx->split_resummed += (int64_t)hmax[i];
+            ctx->split_segments += (int64_t)nb * (cs.total_segs - C);
+        }
         for (int k = 0; k < nb; ++k) {
             double error = 0.0;
             for (int j = 0; j < C; ++j) {
@@ -665,6 +704,13 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
             bound[k0 + k] = kScreenSlack * b / (double)C;
         }
     }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_chain_split(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    ctx->chain_split = on != 0;
     return CCAL_OK;
 }
 

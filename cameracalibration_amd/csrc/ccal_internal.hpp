@@ -68,6 +68,10 @@ struct CloudSet {
 
     // exact path: SoA coordinates of all clouds back to back + block table
     DevBuf xs, ys, zs, blocks, cloud_block_off_dev, cloud_pt_off_dev;
+    // chains cut into parts: per cloud the offset of its 512-element segments in the record arrays, and
+    // the running sums at the segment starts left behind by the last split evaluation (zero: none yet)
+    DevBuf cloud_seg_off_dev, seg_sums;
+    int64_t total_segs = 0;
     std::vector<int> cloud_block_off;  // n_clouds + 1
     int n_blocks = 0;
 
@@ -86,7 +90,7 @@ struct CloudSet {
     void release()
     {
         xs.release(); ys.release(); zs.release(); blocks.release();
-        cloud_block_off_dev.release(); cloud_pt_off_dev.release(); groups.release(); group_off_dev.release();
+        cloud_block_off_dev.release(); cloud_pt_off_dev.release(); cloud_seg_off_dev.release(); seg_sums.release(); groups.release(); group_off_dev.release();
         scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release(); radius_dev.release();
         ready = false;
     }
@@ -110,6 +114,9 @@ struct ccal_ctx {
     ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
     ccal::DevBuf vox[10];                // scratch of the device voxel grid
     ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
+    ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation
+    bool chain_split = true;             // small exact requests cut every chain into parts
+    int64_t split_resummed = 0, split_segments = 0;   // statistics of the split evaluations
     ccal::HostBuf screen_in, screen_out; // four-vectors and per-(pose, cloud) sums of the screening pass
     ccal::DevBuf screen_partial, screen_w;
     bool gd_screening = true;            // line-search trials are first screened on the fast path
@@ -119,8 +126,10 @@ struct ccal_ctx {
 namespace ccal {
 
 // Host-side helpers implemented in ccal_api.hip and used by gd.cpp / ransac.
+// allow_split: the poses are close to those of the previous such call (a descent), so a small request
+// may cut its chains into parts whose units are guessed from that call's sums (same values either way).
 int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
-               double* cost, double* per_cloud_mean, double* per_cloud_max);
+               double* cost, double* per_cloud_mean, double* per_cloud_max, bool allow_split = false);
 
 // Folded FP32 objective of n poses (planes4: per-pose planes, or null for the context's plane)
 // with a bound on its distance from eval_exact's value: |cost[i] - exact cost of pose i| <=

@@ -510,7 +510,7 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             any = true;
             const double t0 = now();
             int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), dim == 10 ? planes.data() : nullptr, f.data(),
-                                      nullptr, nullptr);
+                                      nullptr, nullptr, true);
             t_exact += now() - t0;
             if (rc != CCAL_OK) return rc;
             for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
@@ -518,7 +518,9 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         if (!any) break;
     }
     if (std::getenv("CCAL_GD_STATS"))
-        std::fprintf(stderr, "gd: %.3f s in screening calls, %.3f s in exact calls\n", t_screen, t_exact);
+        std::fprintf(stderr, "gd: %.3f s in screening calls, %.3f s in exact calls; split evaluations summed %lld of %lld "
+                     "segments twice (context totals)\n", t_screen, t_exact, (long long)ctx->split_resummed,
+                     (long long)ctx->split_segments);
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
             std::fprintf(stderr, "gd[%d]: %lld evaluations of the sequential algorithm, %lld evaluated in %lld requests; %lld trials, "

@@ -1489,11 +1489,12 @@ __device__ inline void chain_fold_run(const double d[kChainRun], double scale, u
     }
 }
 
-// Sum (ordered) and, if kWantMax, maximum (:306-307, order-free) of elements
+// Sum (ordered, continuing from s0) and, if kWantMax, maximum (:306-307, order-free) of elements
 // [b, e) of src.  Every thread of the W-wave workgroup returns the same sum; the
 // maximum is valid in thread 0.
 template <int W, bool kWantMax, typename Source>
-__device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, double& out_sum, double& out_max)
+__device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, double s0, double& out_sum,
+                                    double& out_max)
 {
     static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "W must be a power of two");
     constexpr int kPass = kChainSeg * W;
@@ -1513,7 +1514,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
     const int my = wave * kChainSeg + lane * kChainRun;   // this lane's offset inside a pass
     const int64_t b0 = b & ~(int64_t)(kChainRun - 1);
 
-    double s = 0.0, mx = -1e9;                            // :288 error_mx = -1e9
+    double s = s0, mx = -1e9;                             // :288 error_mx = -1e9
     typename Source::Raw raw = src.fetch(b0 + my);
 
     for (int64_t i = b0; i < e; i += kPass) {
@@ -1688,10 +1689,234 @@ __global__ __launch_bounds__(64 * W, 5) void exact_chain_kernel(
 #pragma unroll
     for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
     double sum, mx;
-    chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], sum, mx);
+    chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], 0.0, sum, mx);
     if (threadIdx.x == 0) {
         out_sum[(int64_t)k * n_clouds + j] = sum;
         if (kWantMax) out_max[(int64_t)k * n_clouds + j] = mx;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One chain over several workgroups
+// ---------------------------------------------------------------------------
+// A request of a few dozen poses is a few hundred chains: too few, and too coarse, to fill 256 compute
+// units evenly.  The sequential sum only looks indivisible: an element's map depends on the running sum
+// through its binade (the unit) and its parity alone, and the binade at any place of a chain hardly moves
+// from one evaluation to the next (a descent's poses are close).  So a chain is cut into K parts:
+//   * part 0 starts from zero and is summed as before (most binade crossings are there);
+//   * every other part folds its 512-element segments into maps WITHOUT knowing the sum in front of it,
+//     in the unit that the previous evaluation's sum at that place suggests -- and in the next unit too
+//     where that sum is close to a power of two -- one (unit, map) record per segment;
+//   * a last, short kernel (one wave per chain) walks the records with the true sum: a record is used only
+//     if its unit is the sum's actual binade and the sum stays inside it (sum + increment < 2^53, the very
+//     test of the single-workgroup kernel); any other segment -- the one where the sum leaves its binade, a
+//     wrong guess -- is summed again from the true sum by the sequential routine.  It also leaves the sums
+//     at the segment starts behind for the next evaluation.
+// The result is the sequential sum whatever the guesses were; they only decide how much is summed twice.
+struct SegMap {
+    unsigned long long inc[2][2];   // [unit: the guessed binade, the one above][parity of the sum]
+    int ebiased;                    // biased exponent of the guessed binade
+    unsigned int flags;             // 1: first map usable, 2: second map present, 4: second map usable
+    unsigned long long pad;
+};
+
+constexpr int kSplitWaves = 4;      // waves per workgroup of the part kernel
+
+// segments of a chain's part: the chain's segment count divided by K, rounded up to whole passes
+__device__ __host__ inline int split_part_segments(int n_seg, int K)
+{
+    const int per = (n_seg + K - 1) / K;
+    return (per + kSplitWaves - 1) / kSplitWaves * kSplitWaves;
+}
+
+__global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const int64_t* __restrict__ cloud_pt_off, const int64_t* __restrict__ cloud_seg_off,
+    const double* __restrict__ mats, const double* __restrict__ planes, int n_poses, int n_clouds,
+    int64_t total_pts, int K, const double* __restrict__ sref /* sums at segment starts, previous evaluation */,
+    int64_t total_segs, SegMap* __restrict__ maps /* [pose][segment] */, double* __restrict__ first_sum)
+{
+    const int chain = blockIdx.x / K, c = blockIdx.x % K;
+    const int j = chain / n_poses, k = chain % n_poses;
+    const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
+    const int64_t b0 = b & ~(int64_t)(kChainRun - 1);
+    const int n_seg = (int)((e - b0 + kChainSeg - 1) / kChainSeg);
+    const int per = split_part_segments(n_seg, K);
+    const int s_begin = c * per;
+    if (s_begin >= n_seg) return;
+    const int s_end = s_begin + per < n_seg ? s_begin + per : n_seg;
+
+    DistanceSource src;
+    src.xs = xs; src.ys = ys; src.zs = zs;
+    src.limit = total_pts;
+    const double* M = mats + ((int64_t)k * n_clouds + j) * 12;
+    const double* pl = planes + (int64_t)k * kPlaneStride;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) src.M[i] = M[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
+
+    if (c == 0) {
+        const int64_t e0 = b0 + (int64_t)s_end * kChainSeg;
+        double sum, mx;
+        chain_reduce<kSplitWaves, false>(src, b, e0 < e ? e0 : e, 0.0, sum, mx);
+        if (threadIdx.x == 0) first_sum[(int64_t)k * n_clouds + j] = sum;
+        return;
+    }
+
+    const double two52 = 4503599627370496.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* ref = sref + cloud_seg_off[j];
+    SegMap* out = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
+    for (int seg = s_begin + wave; seg < s_end; seg += kSplitWaves) {
+        const int64_t g0 = b0 + (int64_t)seg * kChainSeg + lane * kChainRun;
+        const DistanceSource::Raw raw = src.fetch(g0);
+        double d[kChainRun];
+        bool finite = src.values(raw, d);
+        if (g0 + kChainRun > e) {                     // the chain's last run(s): elements past the end count as +0.0
+            finite = true;
+#pragma unroll
+            for (int t = 0; t < kChainRun; ++t) {
+                d[t] = g0 + t < e ? d[t] : 0.0;
+                finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+            }
+        }
+        double run_max = d[0];
+#pragma unroll
+        for (int t = 1; t < kChainRun; ++t) run_max = max_f64(run_max, d[t]);
+
+        // the previous evaluation's sums at this segment's ends, widened by 1/64 either way
+        const double lo = ref[seg] * (1.0 - 0.015625), hi = ref[seg + 1] * (1.0 + 0.015625);
+        const int eb_lo = (int)((unsigned long long)__double_as_longlong(lo) >> 52);
+        const int eb_hi = (int)((unsigned long long)__double_as_longlong(hi) >> 52);
+        const bool guess = eb_lo >= 64 && eb_lo <= 1999;      // sign bit set or out of range: no map
+        const bool dual = guess && eb_hi != eb_lo;
+        unsigned long long a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+        bool ok_a = false, ok_b = false;
+        if (guess) {
+            const double scale = __longlong_as_double((long long)((unsigned long long)(2098 - eb_lo) << 52));
+            bool tie = false;
+            bool ok = finite && run_max * scale < two52;
+            if (ok) chain_fold_run(d, scale, a0, a1, tie);
+            if (__any(tie ? 1 : 0)) {
+                chain_compose_wave(a0, a1);
+            } else {
+                for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
+                a1 = a0;
+            }
+            ok_a = __all(ok ? 1 : 0);
+        }
+        if (dual) {
+            const double scale = __longlong_as_double((long long)((unsigned long long)(2097 - eb_lo) << 52));
+            bool tie = false;
+            bool ok = finite && run_max * scale < two52;
+            if (ok) chain_fold_run(d, scale, c0, c1, tie);
+            if (__any(tie ? 1 : 0)) {
+                chain_compose_wave(c0, c1);
+            } else {
+                for (int off = 32; off > 0; off >>= 1) c0 += __shfl_xor(c0, off, 64);
+                c1 = c0;
+            }
+            ok_b = __all(ok ? 1 : 0);
+        }
+        if (lane == 0) {
+            SegMap m;
+            m.inc[0][0] = a0; m.inc[0][1] = a1; m.inc[1][0] = c0; m.inc[1][1] = c1;
+            m.ebiased = guess ? eb_lo : 0;
+            m.flags = (ok_a ? 1u : 0u) | (dual ? 2u : 0u) | (ok_b ? 4u : 0u);
+            m.pad = 0;
+            out[seg] = m;
+        }
+    }
+}
+
+// One wave per chain: the records of split_chain_kernel applied to the true sum (see above).
+__global__ __launch_bounds__(64) void split_finish_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const int64_t* __restrict__ cloud_pt_off, const int64_t* __restrict__ cloud_seg_off,
+    const double* __restrict__ mats, const double* __restrict__ planes, int n_poses, int n_clouds,
+    int64_t total_pts, int K, const SegMap* __restrict__ maps, int64_t total_segs,
+    const double* __restrict__ first_sum, double* __restrict__ sref /* rewritten from pose 0 */,
+    double* __restrict__ out_sum, double* __restrict__ out_resummed)
+{
+    constexpr unsigned long long kTwo53 = 1ull << 53;
+    constexpr unsigned long long kMantissa = (1ull << 52) - 1;
+    const int chain = blockIdx.x;
+    const int j = chain / n_poses, k = chain % n_poses;
+    const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
+    const int64_t b0 = b & ~(int64_t)(kChainRun - 1);
+    const int n_seg = (int)((e - b0 + kChainSeg - 1) / kChainSeg);
+    const int per = split_part_segments(n_seg, K);
+    const int s1 = per < n_seg ? per : n_seg;      // part 0 covered the segments below
+    const int lane = threadIdx.x;
+
+    DistanceSource src;
+    src.xs = xs; src.ys = ys; src.zs = zs;
+    src.limit = total_pts;
+    const double* M = mats + ((int64_t)k * n_clouds + j) * 12;
+    const double* pl = planes + (int64_t)k * kPlaneStride;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) src.M[i] = M[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
+
+    double s = first_sum[(int64_t)k * n_clouds + j];
+    const SegMap* mp = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
+    double* ref = k == 0 ? sref + cloud_seg_off[j] : nullptr;
+    int resummed = 0;
+    for (int base = s1; base < n_seg; base += 64) {
+        const int nl = n_seg - base < 64 ? n_seg - base : 64;
+        SegMap m;
+        m.inc[0][0] = m.inc[0][1] = m.inc[1][0] = m.inc[1][1] = 0;
+        m.ebiased = 0; m.flags = 0; m.pad = 0;
+        if (lane < nl) m = mp[base + lane];
+        int cur = 0;                                // segments base .. base+cur-1 are in s
+        while (cur < nl) {
+            const unsigned long long sbits = (unsigned long long)__double_as_longlong(s);
+            const int eb = (int)(sbits >> 52);      // sign included
+            const bool usable = eb >= 64 && eb <= 2000;
+            const unsigned long long S = (sbits & kMantissa) | (1ull << 52);
+            unsigned long long a0 = 0, a1 = 0;
+            bool valid = false;
+            if (lane >= cur && lane < nl) {
+                if ((m.flags & 1u) && m.ebiased == eb) { a0 = m.inc[0][0]; a1 = m.inc[0][1]; valid = true; }
+                else if ((m.flags & 6u) == 6u && m.ebiased + 1 == eb) { a0 = m.inc[1][0]; a1 = m.inc[1][1]; valid = true; }
+                a0 = a0 < (kTwo53 << 1) ? a0 : (kTwo53 << 1);   // rejected anyway; keeps the scan from wrapping
+                a1 = a1 < (kTwo53 << 1) ? a1 : (kTwo53 << 1);
+            }
+            chain_scan<64>(a0, a1, lane);
+            const unsigned long long tot = (S & 1ull) ? a1 : a0;
+            const bool bad = lane >= cur && lane < nl && (!valid || !usable || S + tot >= kTwo53);
+            const unsigned long long mask = __ballot(bad ? 1 : 0);
+            const int adv = mask ? __builtin_ctzll(mask) : nl;          // first segment that cannot be applied
+            const unsigned long long prev = __shfl_up(tot, 1, 64);
+            if (ref && lane >= cur && lane < adv) {
+                const unsigned long long at = lane > cur ? S + prev : S;
+                ref[base + lane] = __longlong_as_double((long long)((at & kMantissa) | ((unsigned long long)eb << 52)));
+            }
+            if (adv > cur) {
+                const unsigned long long before = __shfl(tot, adv - 1, 64);
+                s = __longlong_as_double((long long)(((S + before) & kMantissa) | ((unsigned long long)eb << 52)));
+            }
+            if (adv < nl) {
+                // this segment again, from the true sum, by the sequential routine
+                if (ref && lane == 0) ref[base + adv] = s;
+                const int64_t sb = b0 + (int64_t)(base + adv) * kChainSeg;
+                const int64_t se = sb + kChainSeg < e ? sb + kChainSeg : e;
+                double s_new, mx;
+                chain_reduce<1, false>(src, sb > b ? sb : b, se, s, s_new, mx);
+                s = s_new;
+                ++resummed;
+                cur = adv + 1;
+            } else {
+                cur = nl;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (ref) ref[n_seg] = s;
+        out_sum[(int64_t)k * n_clouds + j] = s;
+        out_resummed[(int64_t)k * n_clouds + j] = (double)resummed;
     }
 }
 
@@ -1706,7 +1931,7 @@ __global__ __launch_bounds__(64 * kChainWaves) void ordered_sum_kernel(
     src.v = values;
     src.limit = n;
     double sum, mx;
-    chain_reduce<kChainWaves, true>(src, 0, n, sum, mx);
+    chain_reduce<kChainWaves, true>(src, 0, n, 0.0, sum, mx);
     if (threadIdx.x == 0) {
         out_sum[0] = sum;
         out_max[0] = mx;

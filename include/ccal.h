@@ -251,6 +251,12 @@ int  ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_starts,
  * counts and values are the same with screening on or off; off evaluates every trial centre
  * with the reference arithmetic. */
 int  ccal_set_gd_screening(ccal_ctx* ctx, int on);
+/* Chain splitting (on by default; on != 0 enables).  A descent's requests are a few hundred
+ * (pose, cloud) sums of :305, too few to fill the GPU with one workgroup each: every sum is cut into
+ * parts that are folded concurrently in the rounding unit the previous evaluation's running sum
+ * suggests, and a short pass applies them to the true running sum, summing again whatever the
+ * guess did not fit.  Same values on or off (the ordered sum of :305 either way). */
+int  ccal_set_chain_split(ccal_ctx* ctx, int on);
 
 /* ---- host-side ingest and the whole run -------------------------------------
  * These three do not touch the GPU. */

@@ -502,6 +502,39 @@ def test_gradient_descent_screening_changes_nothing(gpu_opt, oracle):
     assert (r.iterations, r.n_evals, r.fval) == (w.iterations, w.n_evals, w.fval)
 
 
+def test_gradient_descent_chain_split_changes_nothing(gpu_opt, oracle):
+    """Every (pose, cloud) sum cut into concurrently folded parts (the default for a descent's requests)
+    gives the bits of the one-workgroup sum: clouds from one segment to several hundred, ragged, with
+    screening on and off, and against the oracle's descent."""
+    import cameracalibration_amd as cc
+    rng = np.random.default_rng(3)
+    for sizes in ([400, 513, 5000], [70000, 150001, 2047, 8192], [30000] * 14):
+        s = make_scene(len(sizes), max(sizes), seed=int(rng.integers(1 << 30)))
+        clouds = [c[:n] for c, n in zip(s.clouds, sizes)]
+        gpu_opt.upload_clouds(0, clouds, s.base_T_flange)
+        gpu_opt.set_plane(s.plane)
+        opts = cc.GdOptions.default()
+        opts.max_iterations = 12
+        res = {}
+        for split in (True, False):
+            for screen in (True, False):
+                gpu_opt.set_chain_split(split)
+                gpu_opt.set_gd_screening(screen)
+                res[split, screen] = gpu_opt.gradient_descent(s.pose_init, opts)
+        gpu_opt.set_chain_split(True)
+        gpu_opt.set_gd_screening(True)
+        ref = res[False, False]
+        for r in res.values():
+            np.testing.assert_array_equal(r.xval, ref.xval)
+            assert (r.iterations, r.n_evals, r.fval) == (ref.iterations, ref.n_evals, ref.fval)
+        if sum(sizes) < 100000:
+            oo = oracle.gd_default_opts()
+            oo.max_iterations = 12
+            w = oracle.OracleScene(clouds, s.base_T_flange).gd_minimize(s.plane, s.pose_init, oo)
+            np.testing.assert_array_equal(ref.xval, np.array(w.xval[:6]))
+            assert (ref.iterations, ref.n_evals, ref.fval) == (w.iterations, w.n_evals, w.fval)
+
+
 def test_multi_start_gd_equals_single_starts(gpu_opt):
     s = make_scene(3, 400, seed=8)
     upload(gpu_opt, s)

@@ -8,6 +8,8 @@ s = make_scene(nc, npts)
 opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
 o = cc.GdOptions.default()
+if os.environ.get('PROBE_NOSPLIT'):
+    opt.set_chain_split(False)
 if os.environ.get('PROBE_NOSCREEN'):
     opt.set_gd_screening(False)
 t = time.time(); r = opt.gradient_descent(s.pose_init, o); print("gd", r.iterations, r.n_evals, r.fval, time.time() - t, flush=True)
