@@ -1736,7 +1736,11 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     int64_t total_pts, int K, const double* __restrict__ sref /* sums at segment starts, previous evaluation */,
     int64_t total_segs, SegMap* __restrict__ maps /* [pose][segment] */, double* __restrict__ first_sum)
 {
-    const int chain = blockIdx.x / K, c = blockIdx.x % K;
+    // Part-major order: consecutive workgroups go to the 8 XCDs in turn, and the workgroups of part 0
+    // (the sequential routine, slower than the others) must not all land on the same ones; they also
+    // start first.
+    const int n_chains = n_poses * n_clouds;
+    const int chain = blockIdx.x % n_chains, c = blockIdx.x / n_chains;
     const int j = chain / n_poses, k = chain % n_poses;
     const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
     const int64_t b0 = b & ~(int64_t)(kChainRun - 1);
@@ -1768,11 +1772,13 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* ref = sref + cloud_seg_off[j];
     SegMap* out = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
+    DistanceSource::Raw raw = src.fetch(b0 + (int64_t)(s_begin + wave) * kChainSeg + lane * kChainRun);
     for (int seg = s_begin + wave; seg < s_end; seg += kSplitWaves) {
         const int64_t g0 = b0 + (int64_t)seg * kChainSeg + lane * kChainRun;
-        const DistanceSource::Raw raw = src.fetch(g0);
         double d[kChainRun];
         bool finite = src.values(raw, d);
+        // the next segment's coordinates are in flight while this one is folded
+        if (seg + kSplitWaves < s_end) raw = src.fetch(g0 + (int64_t)kSplitWaves * kChainSeg);
         if (g0 + kChainRun > e) {                     // the chain's last run(s): elements past the end count as +0.0
             finite = true;
 #pragma unroll
