@@ -621,8 +621,29 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
                          const double* planes4, double* cost, double* per_cloud_mean,
                          double* per_cloud_max)
 {
-    return ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean,
-                            per_cloud_max);
+    // Callers that drive their own optimiser through this entry point (the reference's functor calls
+    // getError pose by pose, :419-426) send runs of nearby poses, which is what the split evaluation
+    // wants; a caller that jumps around makes it sum most segments twice.  So: split, look at how
+    // much was summed twice, and after a bad call stay with whole chains for a while (1, 2, 4, ...
+    // calls) before trying again.
+    if (!ctx) return CCAL_ERR_ARG;
+    bool allow = ctx->chain_split && !per_cloud_max;
+    if (allow && ctx->split_skip > 0) {
+        --ctx->split_skip;
+        allow = false;
+    }
+    const int64_t resummed0 = ctx->split_resummed, segments0 = ctx->split_segments;
+    const int rc = ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean, per_cloud_max, allow);
+    const int64_t segments = ctx->split_segments - segments0;
+    if (rc == CCAL_OK && segments > 0) {
+        if ((ctx->split_resummed - resummed0) * 10 > segments) {
+            ctx->split_skip = ctx->split_penalty;
+            ctx->split_penalty = std::min(256, 2 * ctx->split_penalty);
+        } else {
+            ctx->split_penalty = 1;
+        }
+    }
+    return rc;
 }
 
 // Error budget of the screening pass against the exact objective, per cloud and pose, with

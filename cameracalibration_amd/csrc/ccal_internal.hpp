@@ -117,6 +117,7 @@ struct ccal_ctx {
     ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation
     bool chain_split = true;             // small exact requests cut every chain into parts
     int64_t split_resummed = 0, split_segments = 0;   // statistics of the split evaluations
+    int split_skip = 0, split_penalty = 1;            // ccal_eval: calls to go without splitting after a bad one
     ccal::HostBuf screen_in, screen_out; // four-vectors and per-(pose, cloud) sums of the screening pass
     ccal::DevBuf screen_partial, screen_w;
     bool gd_screening = true;            // line-search trials are first screened on the fast path
