@@ -1870,12 +1870,16 @@ __global__ __launch_bounds__(64) void split_finish_kernel(
     const SegMap* mp = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
     double* ref = k == 0 ? sref + cloud_seg_off[j] : nullptr;
     int resummed = 0;
+    // 64 records per trip, one per lane; the next trip's records are in flight while this one is applied
+    // (a single wave has nothing else to hide the latency behind)
+    SegMap m_next;
+    m_next.inc[0][0] = m_next.inc[0][1] = m_next.inc[1][0] = m_next.inc[1][1] = 0;
+    m_next.ebiased = 0; m_next.flags = 0; m_next.pad = 0;
+    if (s1 + lane < n_seg) m_next = mp[s1 + lane];
     for (int base = s1; base < n_seg; base += 64) {
         const int nl = n_seg - base < 64 ? n_seg - base : 64;
-        SegMap m;
-        m.inc[0][0] = m.inc[0][1] = m.inc[1][0] = m.inc[1][1] = 0;
-        m.ebiased = 0; m.flags = 0; m.pad = 0;
-        if (lane < nl) m = mp[base + lane];
+        const SegMap m = m_next;
+        if (base + 64 + lane < n_seg) m_next = mp[base + 64 + lane];
         int cur = 0;                                // segments base .. base+cur-1 are in s
         while (cur < nl) {
             const unsigned long long sbits = (unsigned long long)__double_as_longlong(s);
