@@ -112,7 +112,8 @@ struct Machine {
     // few dozen poses than for one
     int planned_screen() const
     {
-        int want = last_trials + 8;
+        // the pass works through the poses in tiles of 16: a started tile costs the same full or not
+        int want = (last_trials + 3 + 15) / 16 * 16;
         if (!first_request) want = 16;
         if (want > kMaxSpeculated) want = kMaxSpeculated;
         int n = 1;
