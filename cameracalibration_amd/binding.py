@@ -138,6 +138,7 @@ SIGNATURES = {
     "ccal_get_plane": (C.c_int, [_CTX, _F]),
     "ccal_eval": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, _D, _D]),
     "ccal_eval_fast": (C.c_int, [_CTX, C.c_int, C.c_int64, _D, _F]),
+    "ccal_eval_bounded": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, _D]),
     "ccal_ordered_sum": (C.c_int, [_CTX, _D, C.c_size_t, _D]),
     "ccal_set_fast_kernel": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
@@ -365,6 +366,16 @@ class Optimizer:
             self._lib.ccal_eval_fast(self._ctx, which, P.shape[0], _dptr(P), cost.ctypes.data_as(_F))
         )
         return cost
+
+    def get_error_bounded(self, poses, planes=None, which: int = CCAL_DOWNSAMPLED):
+        """(cost, bound): the FP32 objective and a bound on its distance from get_error's value."""
+        P = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 6)
+        pl = None if planes is None else np.ascontiguousarray(planes, dtype=np.float64).reshape(-1, 4)
+        cost = np.empty(P.shape[0], dtype=np.float64)
+        bound = np.empty(P.shape[0], dtype=np.float64)
+        self._check(self._lib.ccal_eval_bounded(self._ctx, which, P.shape[0], _dptr(P),
+                                                _dptr(pl) if pl is not None else None, _dptr(cost), _dptr(bound)))
+        return cost, bound
 
     # -- search ----------------------------------------------------------------
     def grid_search(self, base_pose, grid: Optional[Grid] = None, begin: int = 0,

@@ -724,10 +724,16 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
                 b += budget[(size_t)k * C + j] + 22.0 * u24 * mean;
             }
             cost[k0 + k] = f / (double)C;
-            bound[k0 + k] = kScreenSlack * b / (double)C;
+            bound[k0 + k] = std::isfinite(b) ? kScreenSlack * b / (double)C : std::numeric_limits<double>::infinity();
         }
     }
     return CCAL_OK;
+}
+
+extern "C" int ccal_eval_bounded(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                                 const double* planes4, double* cost, double* bound)
+{
+    return ccal::eval_screen(ctx, which, n_poses, poses6, planes4, cost, bound);
 }
 
 extern "C" int ccal_set_chain_split(ccal_ctx* ctx, int on)

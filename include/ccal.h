@@ -120,6 +120,15 @@ int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out)
 int ccal_eval_fast(ccal_ctx* ctx, int which, int64_t n_poses, const double* poses6,
                    float* cost);
 
+/* The objective of :280-347 for a few poses on the FP32 path TOGETHER WITH A BOUND on its distance
+ * from ccal_eval's value: whenever both are finite, |cost[i] - ccal_eval cost of pose i| <= bound[i]
+ * (bound[i] is infinite if the set holds a non-finite point).  planes4: per-pose planes as in
+ * ccal_eval, or NULL for the context plane.  This is what decides line-search trials in
+ * ccal_gd_minimize without the reference arithmetic (see ccal_set_gd_screening); exposed so that the
+ * bound can be checked against ccal_eval on arbitrary data. */
+int ccal_eval_bounded(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                      const double* planes4, double* cost, double* bound);
+
 /* Which kernel the fast path runs (no counterpart in the reference):
  *   CCAL_FAST_BF16X3 (default)  operands split exactly into three bf16 pieces,
  *                               contraction on the bf16 matrix pipe, FP32 accumulate;

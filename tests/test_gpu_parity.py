@@ -475,6 +475,46 @@ def test_gradient_descent_line_search_branches(gpu_opt, oracle, tweak):
     assert (r.iterations, r.converged, r.n_evals, r.fval) == (w.iterations, bool(w.converged), w.n_evals, w.fval)
 
 
+def test_screening_bound_holds_and_is_tight_enough(gpu_opt):
+    """The bound that lets line-search trials be decided without the reference arithmetic: it must cover
+    the actual distance between the FP32 objective and ccal_eval on every scene, and stay small enough to
+    be of use (about 5e-4 of the cost on a calibration-like scene; the actual distance is ~1e-7 of it)."""
+    rng = np.random.default_rng(12)
+    s = make_scene(6, 40000, seed=5, ragged=True)
+    upload(gpu_opt, s)
+    poses = np.concatenate([random_poses(s, 40), s.pose_true[None] + rng.normal(0, 1e-5, (8, 6))])
+    fast, bound = gpu_opt.get_error_bounded(poses)
+    exact = gpu_opt.get_error(poses)
+    assert np.all(np.abs(fast - exact) <= bound)
+    assert np.all(bound < 2e-3 * exact) and np.all(np.abs(fast - exact) < 1e-5 * exact)
+    planes = s.plane.astype(np.float64) * 3.0 + rng.normal(0, 1e-3, (len(poses), 4))
+    fast, bound = gpu_opt.get_error_bounded(poses, planes)
+    assert np.all(np.abs(fast - gpu_opt.get_error(poses, planes)) <= bound)
+    # scales over five decades, robot matrices that are not rigid, far-away clouds
+    for trial in range(40):
+        scale = 10.0 ** rng.uniform(-3, 2)
+        n_clouds = int(rng.integers(1, 5))
+        clouds = [(rng.normal(0, scale, (int(rng.integers(1, 9000)), 3)) + rng.normal(0, 5 * scale, 3)).astype(np.float32)
+                  for _ in range(n_clouds)]
+        B = np.stack([__import__("cameracalibration_amd").pose_to_matrix(
+            np.concatenate([rng.normal(0, scale, 3), rng.uniform(-3, 3, 3)])).reshape(16) for _ in range(n_clouds)])
+        if trial % 3 == 0:
+            B[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]] *= 10.0 ** rng.uniform(-1, 1, (n_clouds, 9))
+        gpu_opt.upload_clouds(0, clouds, B)
+        plane = rng.normal(0, 1, 4)
+        plane[3] *= scale
+        gpu_opt.set_plane(plane)
+        poses = np.concatenate([rng.normal(0, scale, (20, 3)), rng.uniform(-3, 3, (20, 3))], axis=1)
+        fast, bound = gpu_opt.get_error_bounded(poses)
+        exact = gpu_opt.get_error(poses)
+        assert np.all(np.abs(fast - exact) <= bound), (trial, scale)
+    # a non-finite point: no bound
+    clouds[0][0, 1] = np.nan
+    gpu_opt.upload_clouds(0, clouds, B)
+    _, bound = gpu_opt.get_error_bounded(poses)
+    assert np.all(np.isinf(bound))
+
+
 def test_gradient_descent_screening_changes_nothing(gpu_opt, oracle):
     """Line-search trials decided from the fast path's score and its error bound (the default) give the
     iterates, counts and values of a descent that evaluates every trial centre exactly, in 6-D and 10-D,
