@@ -428,6 +428,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, cs.seg_sums.ensure((size_t)cs.total_segs * sizeof(double)));
     CCAL_HIP(ctx, hipMemset(cs.seg_sums.p, 0, (size_t)cs.total_segs * sizeof(double)));
+    cs.seg_sums_valid = false;
     cs.radius.assign(n_clouds, 0.0);
     for (int j = 0; j < n_clouds; ++j) {
         float r2;
@@ -511,7 +512,8 @@ static void launch_exact_chains_w(ccal_ctx* ctx, const CloudSet& cs, int n_poses
     hipLaunchKernelGGL((exact_chain_kernel<W, kWantMax>), dim3(n_poses * cs.n_clouds), dim3(64 * W), 0,
                        ctx->stream, cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
                        cs.cloud_pt_off_dev.as<int64_t>(), t.mats, t.planes, n_poses, cs.n_clouds,
-                       (int64_t)cs.total_pts, t.sum, kWantMax ? t.max : nullptr);
+                       (int64_t)cs.total_pts, t.sum, kWantMax ? t.max : nullptr, cs.cloud_seg_off_dev.as<int64_t>(),
+                       cs.seg_sums.as<double>());
 }
 
 // Workgroup width by chain count (measured on 20 x 300k points: 16 waves win below ~128
@@ -577,7 +579,10 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         // Requests too small to fill the chip with whole chains cut every chain into K parts (see
         // split_chain_kernel); hmax's slots then carry the number of segments summed twice.
         const int64_t chains = (int64_t)nb * C;
-        const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu;
+        // (not before some evaluation of this set has left its running sums behind: without them
+        // every segment would be summed again by one wave)
+        const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu &&
+                           cs.seg_sums_valid;
         if (split) {
             // parts per chain: enough workgroups to fill the chip several times over (measured on 620
             // chains: 4 parts 0.578 s, 8 parts 0.562 s, 12 parts 0.560 s per descent)
@@ -599,6 +604,7 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         }
         CCAL_HIP(ctx, hipGetLastError());
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->sets[which].seg_sums_valid = true;
         if (split) {
             for (size_t i = 0; i < n_out; ++i) ctx->split_resummed += (int64_t)hmax[i];
             ctx->split_segments += (int64_t)nb * (cs.total_segs - C);

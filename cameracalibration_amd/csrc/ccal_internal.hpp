@@ -72,6 +72,7 @@ struct CloudSet {
     // the running sums at the segment starts left behind by the last split evaluation (zero: none yet)
     DevBuf cloud_seg_off_dev, seg_sums;
     int64_t total_segs = 0;
+    bool seg_sums_valid = false;        // some evaluation since the upload has written seg_sums
     std::vector<int> cloud_block_off;  // n_clouds + 1
     int n_blocks = 0;
 

@@ -1494,7 +1494,7 @@ __device__ inline void chain_fold_run(const double d[kChainRun], double scale, u
 // maximum is valid in thread 0.
 template <int W, bool kWantMax, typename Source>
 __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, double s0, double& out_sum,
-                                    double& out_max)
+                                    double& out_max, double* seg_out = nullptr)
 {
     static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "W must be a power of two");
     constexpr int kPass = kChainSeg * W;
@@ -1521,6 +1521,9 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
         const int64_t left = e - i;
         const int nelem = left >= kPass ? kPass : (int)left;
         const int nseg = (nelem + kChainSeg - 1) / kChainSeg;
+        // the sum in front of this pass, left as a rough value of the sum at each of its segment
+        // starts (the split evaluation guesses its units from these; the end of the chain follows)
+        if (seg_out && (int)threadIdx.x < nseg) seg_out[(i - b0) / kChainSeg + threadIdx.x] = s;
         double d[kChainRun];
         bool finite = src.values(raw, d);
         if (!(i >= b && i + kPass <= e)) {
@@ -1660,6 +1663,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
         if (threadIdx.x == 0)
             for (int w = 1; w < W; ++w) mx = sh_red[w] > mx ? sh_red[w] : mx;
     }
+    if (seg_out && threadIdx.x == 0) seg_out[(e - b0 + kChainSeg - 1) / kChainSeg] = s;
     out_sum = s;
     out_max = mx;
 }
@@ -1676,7 +1680,8 @@ __global__ __launch_bounds__(64 * W, 5) void exact_chain_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const int64_t* __restrict__ cloud_pt_off, const double* __restrict__ mats,
     const double* __restrict__ planes, int n_poses, int n_clouds, int64_t total_pts,
-    double* __restrict__ out_sum, double* __restrict__ out_max)
+    double* __restrict__ out_sum, double* __restrict__ out_max,
+    const int64_t* __restrict__ cloud_seg_off, double* __restrict__ seg_sums /* null: not wanted */)
 {
     const int j = blockIdx.x / n_poses, k = blockIdx.x % n_poses;
     DistanceSource src;
@@ -1689,7 +1694,9 @@ __global__ __launch_bounds__(64 * W, 5) void exact_chain_kernel(
 #pragma unroll
     for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
     double sum, mx;
-    chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], 0.0, sum, mx);
+    // the first pose's chains leave their running sums behind for a later split evaluation
+    chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], 0.0, sum, mx,
+                              seg_sums && k == 0 ? seg_sums + cloud_seg_off[j] : nullptr);
     if (threadIdx.x == 0) {
         out_sum[(int64_t)k * n_clouds + j] = sum;
         if (kWantMax) out_max[(int64_t)k * n_clouds + j] = mx;
