@@ -2,6 +2,9 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import cameracalibration_amd as cc
+if os.environ.get('PROBE_LIB'):
+    import cameracalibration_amd.binding as _b
+    _b.lib_path = lambda: os.path.abspath(os.environ['PROBE_LIB'])
 from cameracalibration_amd.synthetic import make_scene
 nc, npts = int(sys.argv[1]), int(sys.argv[2])
 s = make_scene(nc, npts)
