@@ -210,6 +210,26 @@ def test_exact_eval_large_clouds_bit_equal(gpu_opt, oracle):
     np.testing.assert_array_equal(gpu_opt.get_error(poses), want)
 
 
+def test_exact_eval_runs_of_nearby_poses_bit_equal(gpu_opt, oracle):
+    """Pose-by-pose calls the way an external optimiser drives ccal_eval (the reference's functor, :419-426):
+    after the first call the chains are cut into parts whose units are guessed from the call before; nearby
+    poses, then a jump, then nearby poses again -- every value is the oracle's."""
+    s = make_scene(3, 120000, seed=43, ragged=True)
+    upload(gpu_opt, s)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    rng = np.random.default_rng(6)
+    poses = [s.pose_init + rng.normal(0, 1e-6, 6) for _ in range(6)]
+    poses += [s.pose_init + np.array([0.03, -0.02, 0.05, 0.2, -0.1, 0.3])]
+    poses += [poses[-1] + rng.normal(0, 1e-7, 6) for _ in range(6)]
+    for split in (True, False):
+        gpu_opt.set_chain_split(split)
+        for p in poses:
+            assert gpu_opt.get_error(p)[0] == o.get_error(p, s.plane)
+        batch = np.stack(poses[:5])
+        np.testing.assert_array_equal(gpu_opt.get_error(batch), [o.get_error(p, s.plane) for p in batch])
+    gpu_opt.set_chain_split(True)
+
+
 def test_exact_eval_with_caller_planes(gpu_opt, oracle):
     s = make_scene(4, 500, seed=11, ragged=True)
     upload(gpu_opt, s)
