@@ -582,7 +582,8 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         // (not before some evaluation of this set has left its running sums behind: without them
         // every segment would be summed again by one wave)
         const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu &&
-                           cs.seg_sums_valid;
+                           cs.seg_sums_valid &&
+                           (int64_t)nb * cs.total_segs * (int64_t)sizeof(SegMap) <= ((int64_t)1 << 30);   // records: at most 1 GiB
         if (split) {
             // parts per chain: enough workgroups to fill the chip several times over (measured on 620
             // chains: 4 parts 0.578 s, 8 parts 0.562 s, 12 parts 0.560 s per descent)
