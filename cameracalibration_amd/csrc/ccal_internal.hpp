@@ -113,7 +113,7 @@ struct ccal_ctx {
     // scratch (grow-only)
     ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
     ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
-    ccal::DevBuf vox[10];                // scratch of the device voxel grid
+    ccal::DevBuf vox[13];                // scratch of the device voxel grid
     ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
     ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation
     bool chain_split = true;             // small exact requests cut every chain into parts

@@ -4,7 +4,10 @@
 // (leaf 0.02f) with the same definition as the host filter (csrc/host/cloud_io.cpp): PCL's
 // index arithmetic in float, voxels emitted in ascending linear index, the points of a voxel
 // accumulated in input order in float.  Per cloud: bounds reduction -> keys -> stable radix
-// sort of (key, point index) -> run-length encode -> one thread per voxel sums its run.
+// sort of (key, point index) -> run-length encode -> coordinates gathered in sorted order; then ONE
+// launch for the voxels of all clouds, one thread per voxel summing its run in order (a cloud has
+// only a few hundred voxels of thousands of points each: per cloud that launch would be a few
+// hundred threads adding for a long time).
 #pragma once
 
 #include <rocprim/rocprim.hpp>
@@ -93,16 +96,30 @@ __global__ __launch_bounds__(256) void voxel_gather_kernel(const float* __restri
     gz[t] = zs[i];
 }
 
+// The run table of one cloud appended to the table of all clouds (offsets become global).
+__global__ __launch_bounds__(256) void voxel_append_runs_kernel(const unsigned int* __restrict__ counts,
+                                                                const unsigned int* __restrict__ offsets,
+                                                                unsigned int n_runs, unsigned long long base,
+                                                                unsigned int* __restrict__ all_counts,
+                                                                unsigned long long* __restrict__ all_offsets)
+{
+    const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_runs) return;
+    all_counts[v] = counts[v];
+    all_offsets[v] = base + offsets[v];
+}
+
 // One thread per voxel: float sums of its run in order (one add at a time, as a serial filter
 // does); eight elements are in flight per trip so the loads do not wait for the adds.
 __global__ __launch_bounds__(64) void voxel_centroid_kernel(
     const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
-    const unsigned int* __restrict__ counts, const unsigned int* __restrict__ offsets, unsigned int n_runs,
+    const unsigned int* __restrict__ counts, const unsigned long long* __restrict__ offsets, unsigned int n_runs,
     float* __restrict__ out /* AoS xyz */)
 {
     const unsigned int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_runs) return;                     // the host passes only the runs of real cells
-    const unsigned int o = offsets[v], c = counts[v];
+    const unsigned long long o = offsets[v];
+    const unsigned int c = counts[v];
     float sx = 0.f, sy = 0.f, sz = 0.f;
     unsigned int t = 0;
     for (; t + 8 <= c; t += 8) {
@@ -123,10 +140,30 @@ __global__ __launch_bounds__(64) void voxel_centroid_kernel(
 
 namespace {
 
-// Voxel centroids of points [begin, begin+n) of a resident set, appended to `out`.
-int voxel_downsample_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int64_t n, float leaf,
-                           std::vector<float>& out)
+// Grow a device buffer to `need` bytes keeping its first `keep` bytes.
+hipError_t grow_keeping(ccal::DevBuf& b, size_t need, size_t keep, hipStream_t st)
 {
+    if (need <= b.bytes) return hipSuccess;
+    ccal::DevBuf bigger;
+    hipError_t e = bigger.ensure(need + need / 2);
+    if (e != hipSuccess) return e;
+    if (keep) {
+        e = hipMemcpyAsync(bigger.p, b.p, keep, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { bigger.release(); return e; }
+    }
+    b.release();
+    b = bigger;
+    return hipSuccess;
+}
+
+// Voxels of points [begin, begin+n) of a resident set: their runs (count, offset into the gathered
+// coordinates of the whole set) are appended to the run table of the call at position `used`;
+// *n_vox_out = how many.  The centroids are formed afterwards, for all clouds at once.
+int voxel_runs_of_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int64_t n, float leaf, size_t used,
+                        unsigned int* n_vox_out)
+{
+    *n_vox_out = 0;
     hipStream_t st = ctx->stream;
     const float* xs = cs.xs.as<float>();
     const float* ys = cs.ys.as<float>();
@@ -172,7 +209,9 @@ int voxel_downsample_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int
     DevBuf& offsets = ctx->vox[6];
     DevBuf& nruns = ctx->vox[7];
     DevBuf& tmp = ctx->vox[8];
-    DevBuf& cent = ctx->vox[9];
+    DevBuf& gathered = ctx->vox[10];      // x | y | z of the whole set in sorted order, sized by the caller
+    DevBuf& all_counts = ctx->vox[11];
+    DevBuf& all_offsets = ctx->vox[12];
     CCAL_HIP(ctx, keys.ensure(N * 8)); CCAL_HIP(ctx, keys2.ensure(N * 8));
     CCAL_HIP(ctx, idx.ensure(N * 4)); CCAL_HIP(ctx, idx2.ensure(N * 4));
     CCAL_HIP(ctx, uniq.ensure(N * 8)); CCAL_HIP(ctx, counts.ensure(N * 4));
@@ -210,22 +249,20 @@ int voxel_downsample_range(ccal_ctx* ctx, const CloudSet& cs, int64_t begin, int
     CCAL_HIP(ctx, hipMemcpyAsync(&last_key, uniq.as<unsigned long long>() + (n_runs - 1), 8, hipMemcpyDeviceToHost, st));
     CCAL_HIP(ctx, hipStreamSynchronize(st));
     const unsigned int n_vox = last_key == d.nonfinite_key ? n_runs - 1 : n_runs;
-    CCAL_HIP(ctx, cent.ensure((size_t)std::max(1u, n_vox) * 3 * sizeof(float)));
     if (n_vox) {
-        // keys/keys2 are free after the run-length encode: they hold the gathered coordinates
-        float* gx = keys.as<float>();
-        float* gy = gx + N;
-        float* gz = keys2.as<float>();
+        const size_t total = cs.total_pts;
+        float* gx = gathered.as<float>() + begin;
         hipLaunchKernelGGL(voxel_gather_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xs, ys, zs, begin,
-                           idx2.as<unsigned int>(), n, gx, gy, gz);
-        hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_vox + 63) / 64), dim3(64), 0, st, gx, gy, gz,
-                           counts.as<unsigned int>(), offsets.as<unsigned int>(), n_vox, cent.as<float>());
+                           idx2.as<unsigned int>(), n, gx, gx + total, gx + 2 * total);
+        CCAL_HIP(ctx, grow_keeping(all_counts, (used + n_vox) * sizeof(unsigned int), used * sizeof(unsigned int), st));
+        CCAL_HIP(ctx, grow_keeping(all_offsets, (used + n_vox) * sizeof(unsigned long long),
+                                   used * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(voxel_append_runs_kernel, dim3((n_vox + 255) / 256), dim3(256), 0, st, counts.as<unsigned int>(),
+                           offsets.as<unsigned int>(), n_vox, (unsigned long long)begin, all_counts.as<unsigned int>() + used,
+                           all_offsets.as<unsigned long long>() + used);
         CCAL_HIP(ctx, hipGetLastError());
-        const size_t o = out.size();
-        out.resize(o + (size_t)n_vox * 3);
-        CCAL_HIP(ctx, hipMemcpyAsync(out.data() + o, cent.p, (size_t)n_vox * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
-        CCAL_HIP(ctx, hipStreamSynchronize(st));
     }
+    *n_vox_out = n_vox;
     return CCAL_OK;
 }
 
@@ -238,18 +275,35 @@ extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
     if (int rc = bind(ctx)) return rc;
     const CloudSet& raw = ctx->sets[CCAL_RAW];
     const int C = raw.n_clouds;
-    std::vector<std::vector<float>> down(C);
+    CCAL_HIP(ctx, ctx->vox[10].ensure(3 * raw.total_pts * sizeof(float)));
+    std::vector<unsigned int> n_vox(C, 0);
+    size_t used = 0;
     int64_t begin = 0;
     for (int j = 0; j < C; ++j) {
-        if (int rc = voxel_downsample_range(ctx, raw, begin, (int64_t)raw.n_pts[j], leaf, down[j])) return rc;
+        if (int rc = voxel_runs_of_range(ctx, raw, begin, (int64_t)raw.n_pts[j], leaf, used, &n_vox[j])) return rc;
         begin += (int64_t)raw.n_pts[j];
-        if (down[j].empty()) return fail(ctx, CCAL_ERR_ARG, "downsample_raw: a cloud has no finite point");
+        if (n_vox[j] == 0) return fail(ctx, CCAL_ERR_ARG, "downsample_raw: a cloud has no finite point");
+        used += n_vox[j];
     }
+    if (used >= ((size_t)1 << 32)) return fail(ctx, CCAL_ERR_CAPACITY, "downsample_raw: too many voxels");
+    // the centroids of all clouds in one launch
+    DevBuf& cent = ctx->vox[9];
+    CCAL_HIP(ctx, cent.ensure(used * 3 * sizeof(float)));
+    const float* gx = ctx->vox[10].as<float>();
+    hipLaunchKernelGGL(voxel_centroid_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64), 0, ctx->stream, gx,
+                       gx + raw.total_pts, gx + 2 * raw.total_pts, ctx->vox[11].as<unsigned int>(),
+                       ctx->vox[12].as<unsigned long long>(), (unsigned int)used, cent.as<float>());
+    CCAL_HIP(ctx, hipGetLastError());
+    std::vector<float> down(used * 3);
+    CCAL_HIP(ctx, hipMemcpyAsync(down.data(), cent.p, down.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<const float*> ptrs(C);
     std::vector<size_t> sizes(C);
+    size_t at = 0;
     for (int j = 0; j < C; ++j) {
-        ptrs[j] = down[j].data();
-        sizes[j] = down[j].size() / 3;
+        ptrs[j] = down.data() + 3 * at;
+        sizes[j] = n_vox[j];
+        at += n_vox[j];
         if (n_pts_out) n_pts_out[j] = sizes[j];
     }
     const std::vector<double> B = raw.base_T_flange;   // upload replaces sets[which] only, copy is defensive
