@@ -390,9 +390,14 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, cs.radius_dev.ensure(n_clouds * sizeof(unsigned int)));
     CCAL_HIP(ctx, hipMemsetAsync(cs.radius_dev.p, 0, n_clouds * sizeof(unsigned int), ctx->stream));
     std::vector<unsigned int> radius2_bits(n_clouds, 0u);
+    std::vector<size_t> rblock_off(n_clouds + 1, 0);
+    for (int j = 0; j < n_clouds; ++j) rblock_off[j + 1] = rblock_off[j] + (n_pts[j] + 255) / 256;
+    std::vector<float> radius_sums(rblock_off[n_clouds], 0.f);
+    DevBuf radius_sums_dev;   // per tiling block: sum of its points' distances from the centre
     {
         DevBuf stage;   // the AoS copy lives only for this call
         hipError_t e = stage.ensure(total * 3 * sizeof(float));
+        if (e == hipSuccess) e = radius_sums_dev.ensure(radius_sums.size() * sizeof(float));
         for (int j = 0; j < n_clouds && e == hipSuccess; ++j) {
             float* dst = stage.as<float>() + 3 * (size_t)pt_off[j];
             e = hipMemcpyAsync(dst, xyz[j], n_pts[j] * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
@@ -400,14 +405,19 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
                                dst, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j], cs.centres[3 * j],
                                cs.centres[3 * j + 1], cs.centres[3 * j + 2], cs.xs.as<float>(), cs.ys.as<float>(),
-                               cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j);
+                               cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j,
+                               radius_sums_dev.as<float>() + rblock_off[j]);
         }
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess)
             e = hipMemcpyAsync(radius2_bits.data(), cs.radius_dev.p, n_clouds * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(radius_sums.data(), radius_sums_dev.p, radius_sums.size() * sizeof(float),
+                               hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         stage.release();
+        radius_sums_dev.release();
         CCAL_HIP(ctx, e);
     }
     CCAL_HIP(ctx, cs.blocks.ensure(blocks.size() * sizeof(BlockDesc)));
@@ -435,6 +445,28 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
         std::memcpy(&r2, &radius2_bits[j], sizeof r2);
         // FP32 evaluation of the squared length: a few ulps, covered by the factor
         cs.radius[j] = std::isfinite(r2) ? std::sqrt((double)r2) * (1.0 + 1e-6) : std::numeric_limits<double>::infinity();
+    }
+    // mean distance from the centre (float square roots and block sums: the factor covers their roundings)
+    // and a bound on the 2-norm of the robot pose's 3x3 part: 1 for a rotation, else its Frobenius norm
+    cs.radius_mean.assign(n_clouds, 0.0);
+    cs.rot_norm.assign(n_clouds, 0.0);
+    for (int j = 0; j < n_clouds; ++j) {
+        double sum = 0.0;
+        for (size_t b = rblock_off[j]; b < rblock_off[j + 1]; ++b) sum += (double)radius_sums[b];
+        cs.radius_mean[j] = std::isfinite(cs.radius[j]) && std::isfinite(sum)
+                                ? std::min(cs.radius[j], sum / (double)n_pts[j] * (1.0 + 1e-5))
+                                : std::numeric_limits<double>::infinity();
+        const double* B = base_T_flange + 16 * (size_t)j;
+        double off = 0.0, fro = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double g = 0.0;
+                for (int k = 0; k < 3; ++k) g += B[k * 4 + a] * B[k * 4 + b];
+                off = std::max(off, std::fabs(g - (a == b ? 1.0 : 0.0)));
+                fro += B[a * 4 + b] * B[a * 4 + b];
+            }
+        cs.rot_norm[j] = off <= 1e-6 ? 1.0 + 2e-6 : std::sqrt(fro);
+        if (!std::isfinite(cs.rot_norm[j])) cs.rot_norm[j] = std::numeric_limits<double>::infinity();
     }
     cs.split_ready = false;
     if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)
@@ -654,10 +686,11 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 }
 
 // Error budget of the screening pass against the exact objective, per cloud and pose, with
-// rho = largest distance of a point from the cloud's centre c, m = |M (c,1)| (the centre carried to the
-// base frame) and w4 = the folded constant (the signed distance of the centre):
+// rho = MEAN distance of the cloud's points from its centre c (the budgets below are per point and linear
+// in |p - c|; the objective is a mean over the points), m = |M (c,1)| (the centre carried to the base
+// frame) and w4 = the folded constant (the signed distance of the centre):
 //   exact path:  rounds every transformed coordinate to float (src/helpers.hpp:151): the residual moves by at
-//                most 2^-24 |q| <= 2^-24 (|R|_F rho + m)                (Cauchy-Schwarz with the unit normal;
+//                most 2^-24 |q| <= 2^-24 (|R|_2 rho + m)                (Cauchy-Schwarz with the unit normal;
 //                                                                       R = the 3x3 part of M)
 //   fast path:   w and p - c rounded to float, four roundings in the chain, each on a magnitude of at most
 //                |w123||p - c| + |w4| <= |w123| rho + |w4|:  6 * 2^-24 (|w123| rho + |w4|)
@@ -699,17 +732,19 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
                 double wv[4];
                 fold_plane(M, pl, pl[3], inv_norm, c, wv);
                 for (int e = 0; e < 4; ++e) w[((size_t)k * C + j) * 4 + e] = (float)wv[e];
-                // |q| <= |R|_F rho + |M (c,1)| for the transformed point, |w123 . (p - c)| <= |w123| rho
-                // (the robot poses are whatever the caller uploaded: no norm is taken for granted)
-                double m2 = 0.0, r2 = 0.0;
+                // |q_i| <= |R|_2 |p_i - c| + |M (c,1)| for a transformed point and |w123 . (p_i - c)| <=
+                // |w123| |p_i - c|: both budgets are linear in |p_i - c|, and the objective is a mean over the
+                // points, so the MEAN distance from the centre enters.  R = (robot pose) * (a rotation): its
+                // 2-norm is at most that of the robot pose's 3x3 part, whatever the caller uploaded.
+                double m2 = 0.0;
                 for (int r = 0; r < 3; ++r) {
                     const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
                     m2 += q * q;
-                    r2 += M[r * 4] * M[r * 4] + M[r * 4 + 1] * M[r * 4 + 1] + M[r * 4 + 2] * M[r * 4 + 2];
                 }
-                const double rho = cs.radius[j];
+                const double rho = cs.radius_mean[j];
+                const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
                 const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
-                budget[(size_t)k * C + j] = u24 * (std::sqrt(r2) * rho + std::sqrt(m2)) + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
+                budget[(size_t)k * C + j] = u24 * (rn * rho + std::sqrt(m2)) + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
             }
         }
         // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)

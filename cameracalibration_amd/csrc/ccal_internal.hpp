@@ -84,6 +84,8 @@ struct CloudSet {
     std::vector<double> centres;       // n_clouds * 3
     DevBuf radius_dev;                 // per cloud: bits of the largest squared distance from the centre
     std::vector<double> radius;        // per cloud: that distance (infinity if a point is not finite)
+    std::vector<double> radius_mean;   // per cloud: mean distance from the centre (same convention)
+    std::vector<double> rot_norm;      // per cloud: bound on the 2-norm of the robot pose's 3x3 part
     int64_t n_groups = 0;
     int64_t n_pad_points = 0;          // zero points added to fill the last groups
     int min_groups = 0;

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
                                                          double cx, double cy, double cz,
                                                          float* __restrict__ xs, float* __restrict__ ys,
                                                          float* __restrict__ zs, float* __restrict__ groups,
-                                                         unsigned int* __restrict__ radius2_bits /* this cloud */)
+                                                         unsigned int* __restrict__ radius2_bits /* this cloud */,
+                                                         float* __restrict__ radius_sums /* this cloud: one per block */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float r2 = 0.f;
@@ -80,6 +81,11 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
     }
     // largest squared distance from the centre: non-negative floats order like their bit patterns,
     // and a NaN's pattern lies above infinity's, so a non-finite point leaves a non-finite mark
+    // sum of the distances from the centre, per block in a fixed order (the host adds the blocks)
+    __shared__ float wave_sums[4];
+    float rs = __builtin_sqrtf(r2);
+    for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = rs;
     __shared__ unsigned int wave_bits[4];
     unsigned int bits = __float_as_uint(r2);
     for (int off = 32; off > 0; off >>= 1) {
@@ -91,6 +97,7 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) bits = wave_bits[w] > bits ? wave_bits[w] : bits;
         atomicMax(radius2_bits, bits);
+        radius_sums[blockIdx.x] = ((wave_sums[0] + wave_sums[1]) + wave_sums[2]) + wave_sums[3];
     }
 }
 
