@@ -689,9 +689,10 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 // rho = MEAN distance of the cloud's points from its centre c (the budgets below are per point and linear
 // in |p - c|; the objective is a mean over the points), m = |M (c,1)| (the centre carried to the base
 // frame) and w4 = the folded constant (the signed distance of the centre):
-//   exact path:  rounds every transformed coordinate to float (src/helpers.hpp:151): the residual moves by at
-//                most 2^-24 |q| <= 2^-24 (|R|_2 rho + m)                (Cauchy-Schwarz with the unit normal;
-//                                                                       R = the 3x3 part of M)
+//   exact path:  rounds every transformed coordinate q_r to float (src/helpers.hpp:151), and the distance weighs
+//                coordinate r with |n_r|/|n|: the residual moves by at most
+//                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 |p - c|)
+//                                                                       (R = the 3x3 part of M)
 //   fast path:   w and p - c rounded to float, four roundings in the chain, each on a magnitude of at most
 //                |w123||p - c| + |w4| <= |w123| rho + |w4|:  6 * 2^-24 (|w123| rho + |w4|)
 //   sums:        16 + 6 FP32 adds per partial:  22 * 2^-24 of the cloud's mean residual
@@ -736,15 +737,18 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
                 // |w123| |p_i - c|: both budgets are linear in |p_i - c|, and the objective is a mean over the
                 // points, so the MEAN distance from the centre enters.  R = (robot pose) * (a rotation): its
                 // 2-norm is at most that of the robot pose's 3x3 part, whatever the caller uploaded.
-                double m2 = 0.0;
-                for (int r = 0; r < 3; ++r) {
-                    const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
-                    m2 += q * q;
-                }
+                // The float rounding of the exact path acts on each coordinate of q, and the distance weighs
+                // coordinate r with |n_r| / |n|: sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 rho) -- for a plane
+                // that is roughly level this is far below |q|, which is mostly horizontal offset.
                 const double rho = cs.radius_mean[j];
                 const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
+                double ex = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
+                    ex += std::fabs(pl[r]) * inv_norm * (std::fabs(q) + rn * rho);
+                }
                 const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
-                budget[(size_t)k * C + j] = u24 * (rn * rho + std::sqrt(m2)) + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
+                budget[(size_t)k * C + j] = u24 * ex + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
             }
         }
         // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)
