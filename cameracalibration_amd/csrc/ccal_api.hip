@@ -693,8 +693,9 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 //                coordinate r with |n_r|/|n|: the residual moves by at most
 //                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 |p - c|)
 //                                                                       (R = the 3x3 part of M)
-//   fast path:   w and p - c rounded to float, four roundings in the chain, each on a magnitude of at most
-//                |w123||p - c| + |w4| <= |w123| rho + |w4|:  6 * 2^-24 (|w123| rho + |w4|)
+//   fast path:   w and p - c rounded to float (one rounding each), then three fused multiply-adds (the
+//                innermost product is by exactly 1 and does not round), each on a magnitude of at most
+//                |w123||p - c| + |w4|:  5 * 2^-24 (|w123| rho + |w4|)
 //   sums:        16 + 6 FP32 adds per partial:  22 * 2^-24 of the cloud's mean residual
 // The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
 constexpr double kScreenSlack = 1.25;
@@ -748,7 +749,7 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
                     ex += std::fabs(pl[r]) * inv_norm * (std::fabs(q) + rn * rho);
                 }
                 const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
-                budget[(size_t)k * C + j] = u24 * ex + 6.0 * u24 * (wn * rho + std::fabs(wv[3]));
+                budget[(size_t)k * C + j] = u24 * ex + 5.0 * u24 * (wn * rho + std::fabs(wv[3]));
             }
         }
         // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)
