@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--clouds", type=int, default=20)
     ap.add_argument("--points", type=int, default=300_000)
     ap.add_argument("--axis", type=int, default=10, help="grid steps per axis (10 -> 10^6 candidates)")
-    ap.add_argument("--cpu-candidates", type=int, default=256,
+    ap.add_argument("--cpu-candidates", type=int, default=512,
                     help="candidates of the workload scored by the CPU oracle for cpu_baseline (0 = skip)")
     ap.add_argument("--kernel", choices=["bf16x3", "f32", "bf16x3wide"], default="bf16x3",
                     help="fast-path kernel: exact bf16x3 operand split on the bf16 matrix pipe, or FP32-input MFMA")
