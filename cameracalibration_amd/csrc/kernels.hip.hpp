@@ -28,6 +28,7 @@
 namespace ccal {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------
 // Layouts
@@ -1152,6 +1153,8 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
     const int g1 = group_off[j] + (int)((le + kGroupPoints - 1) / kGroupPoints);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, gsel = lane >> 4;
+    // The fourth row of a group (1 for a point, 0 for padding) is not loaded: it follows from the point's index.
+    const int64_t n_j = cloud_pt_off[j + 1] - cloud_pt_off[j];
     f32x4 X[4], Y[4], Z[4], O[4];
 #pragma unroll
     for (int trip = 0; trip < 4; ++trip) {
@@ -1160,7 +1163,10 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
         X[trip] = Y[trip] = Z[trip] = O[trip] = zero;   // absent groups add |0|
         if (g < g1) {
             const f32x4* gp = groups + (int64_t)g * 64 + col;
-            X[trip] = gp[0]; Y[trip] = gp[16]; Z[trip] = gp[32]; O[trip] = gp[48];
+            X[trip] = gp[0]; Y[trip] = gp[16]; Z[trip] = gp[32];
+            const int64_t first = (int64_t)(g - group_off[j]) * kGroupPoints + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) O[trip][u] = first + u * kTilePoints < n_j ? 1.f : 0.f;
         }
     }
     for (int p0 = 0; p0 < n_poses; p0 += kScreenTile) {
@@ -1169,14 +1175,20 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
         for (int t = 0; t < kScreenTile; ++t) {
             const int p = p0 + t < n_poses ? p0 + t : n_poses - 1;   // a short last tile repeats its last pose
             const f32x4 wv = w[(int64_t)p * n_clouds + j];
+            // two residuals per instruction (packed FP32); each still is the chain product, fma, fma, fma,
+            // and the lane adds them in point order
+            const f32x2 w0 = {wv[0], wv[0]}, w1 = {wv[1], wv[1]}, w2 = {wv[2], wv[2]}, w3 = {wv[3], wv[3]};
             float a = 0.f;
 #pragma unroll
             for (int trip = 0; trip < 4; ++trip)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float r = __builtin_fmaf(wv[0], X[trip][u], __builtin_fmaf(wv[1], Y[trip][u],
-                                    __builtin_fmaf(wv[2], Z[trip][u], wv[3] * O[trip][u])));
-                    a += __builtin_fabsf(r);
+                for (int h = 0; h < 4; h += 2) {
+                    const f32x2 x = {X[trip][h], X[trip][h + 1]}, y = {Y[trip][h], Y[trip][h + 1]};
+                    const f32x2 z = {Z[trip][h], Z[trip][h + 1]}, o = {O[trip][h], O[trip][h + 1]};
+                    const f32x2 r = __builtin_elementwise_fma(w0, x, __builtin_elementwise_fma(w1, y,
+                                    __builtin_elementwise_fma(w2, z, w3 * o)));
+                    a += __builtin_fabsf(r[0]);
+                    a += __builtin_fabsf(r[1]);
                 }
             acc[t] = a;
         }
