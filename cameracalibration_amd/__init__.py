@@ -20,6 +20,8 @@ from .binding import (  # noqa: F401
     GridStats,
     Optimizer,
     device_count,
+    filter_z,
+    parse_pose,
     grid_pose,
     lib_path,
     load_library,

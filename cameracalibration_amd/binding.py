@@ -73,6 +73,8 @@ class GridStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("kernel_launches", C.c_int),
         ("total_ms", C.c_double),
+        ("band_abs", C.c_double),
+        ("band_rel", C.c_double),
     ]
 
 
@@ -154,6 +156,7 @@ SIGNATURES = {
         [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _P(C.c_int64), _D, _D, _P(GridStats)],
     ),
     "ccal_grid_costs": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _F]),
+    "ccal_grid_error_bound": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), _D, _D]),
     "ccal_argmin_merge": (C.c_int, [C.c_int, _D, _P(C.c_int64)]),
     "ccal_fit_plane_lsq": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_ransac_plane": (
@@ -170,6 +173,8 @@ SIGNATURES = {
     "ccal_read_point_cloud": (C.c_int, [C.c_char_p, C.c_char_p, _P(_F), _P(C.c_size_t)]),
     "ccal_voxel_grid": (C.c_int, [_F, C.c_size_t, C.c_float, _F, _P(C.c_size_t)]),
     "ccal_free": (None, [C.c_void_p]),
+    "ccal_parse_pose": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _D]),
+    "ccal_filter_z": (C.c_int, [_F, C.c_size_t, C.c_double, _F, _P(C.c_size_t)]),
     "ccal_run_config": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
 }
 
@@ -409,6 +414,14 @@ class Optimizer:
                                               out.ctypes.data_as(_F)))
         return out
 
+    def grid_error_bound(self, base_pose, grid: Optional[Grid] = None, which: int = CCAL_DOWNSAMPLED):
+        """(abs, rel): |grid_costs value - get_error value| <= abs + rel * grid_costs value on the whole grid."""
+        g = grid if grid is not None else Grid.default()
+        b = np.ascontiguousarray(base_pose, dtype=np.float64)
+        a, r = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.ccal_grid_error_bound(self._ctx, which, _dptr(b), C.byref(g), C.byref(a), C.byref(r)))
+        return float(a.value), float(r.value)
+
     def fit_plane(self, pose, which: int = CCAL_RAW) -> np.ndarray:
         p = np.ascontiguousarray(pose, dtype=np.float64)
         out = np.empty(4, dtype=np.float32)
@@ -476,6 +489,27 @@ def voxel_grid(xyz: np.ndarray, leaf: float = 0.02) -> np.ndarray:
                                         out.ctypes.data_as(_F), C.byref(n))
     if rc != 0:
         raise CcalError(rc, "voxel_grid")
+    return out[: n.value].copy()
+
+
+def parse_pose(value_csv: str, metric: str = "m", angle: str = "rad") -> np.ndarray:
+    """getTransVector (camera_calibration_optimization.cpp:70-98): CSV -> (tx,ty,tz,rz,ry,rx) in m / rad."""
+    out = np.zeros(6, dtype=np.float64)
+    rc = load_library().ccal_parse_pose(value_csv.encode(), metric.encode(), angle.encode(), _dptr(out))
+    if rc != 0:
+        raise CcalError(rc, f"cannot parse pose '{value_csv}'")
+    return out
+
+
+def filter_z(xyz: np.ndarray, z_max: float = 0.8) -> np.ndarray:
+    """The depth cut `pts.z<=0.8` of camera_calibration_optimization.cpp:167-169 (double comparison)."""
+    a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    out = np.empty_like(a)
+    n = C.c_size_t(0)
+    rc = load_library().ccal_filter_z(a.ctypes.data_as(_F), a.shape[0], float(z_max),
+                                      out.ctypes.data_as(_F), C.byref(n))
+    if rc != 0:
+        raise CcalError(rc, "filter_z")
     return out[: n.value].copy()
 
 

@@ -85,8 +85,7 @@ int check_set(ccal_ctx* ctx, int which)
 constexpr int kPointsPerBlock = 256 * 16;  // exact path: points handled by one block
 constexpr int kNA = 8;                      // candidate tiles per wave on the fast path
 constexpr int kCandPerBlock = 4 * kNA * 16; // 512
-constexpr unsigned kBandCap = 1u << 16;     // max near-minimum candidates re-scored
-constexpr float kBand = 1e-4f;              // relative band around the fast-path minimum
+constexpr unsigned kBandCap = 1u << 16;     // near-minimum candidates re-scored per pass
 
 // Rows 0..2 of base_T_flange_j * F(pose) for every cloud, [n_clouds][12].
 void pose_matrices(const CloudSet& cs, const double pose[6], double* mats)
@@ -1110,18 +1109,114 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     return CCAL_OK;
 }
 
+// How far a fast-path cost of the grid can lie from the reference-arithmetic cost of the same
+// candidate: |fast(c) - exact(c)| <= abs_err + rel_err * fast(c) for EVERY candidate of the grid
+// box (not only those of one shard), so that the set {c : fast(c)(1 - rel) <= min fast (1 + rel) +
+// 2 abs} is certain to hold the reference-arithmetic arg-min and all its ties.  Per cloud, with
+// rho = mean distance of the points from the centre c_j, rn >= |R_j|_2, u = 2^-24, and over the box
+//   D    = |c_j| * (sum of the largest angle offsets) + |largest translation offset|
+//          >= |F(cand)(c_j,1) - F(base)(c_j,1)|   (|Rz'Ry'Rx' - RzRyRx| <= sum |angle differences|)
+//   q_r  <= |q_r(base)| + |row_r(R_j)| D           (centre carried to the base frame, coordinate r)
+//   w4   <= |w4(base)| + sum_r |n_r|/|n| |row_r(R_j)| D    (signed distance of the carried centre)
+// the budgets are
+//   reference side: every coordinate of the transformed point rounded to float (src/helpers.hpp:151):
+//                u * sum_r |n_r|/|n| (q_r + rn rho)
+//   dense kernels:  w and p - c rounded to float (2u), then the contraction.  FP32-input matrix
+//                instruction: an fmaf chain, 4 roundings.  bf16 forms: products of bf16 pairs are exact;
+//                the 32 (+2 chained) FP32 accumulation steps inside the matrix pipe are budgeted
+//                at one ulp (2u) each, truncation included, and the dropped low*low term at u.
+//                All on magnitudes <= rn |p - c| + w4.
+//   accumulation:   128 FP32 adds per lane partial + 4 in the promotion, of non-negative terms:
+//                relative 132u of the sum; one more u for the float the cost is stored as.
+//   separable pass: w, p - c, the rotation constant a and the translation constant b rounded to float,
+//                a four-rounding FP32 chain on magnitudes <= rn |p - c| + |a|, 2^-32 m fixed point
+//                (rounding, and the sign taken from the unrounded value): u (6 rn rho + 5 A + B) + 2^-31
+//                with A >= |a| (the carried centre's distance at the middle translation: <= w4 above)
+//                and B = 2 rn |largest translation offset| >= |b - b_ref|; integer sums add nothing.
+// The FP64 arithmetic on both sides is below 1e-12 of these magnitudes; kScreenSlack covers it.
+// separable_ok: the separable kernel keeps residuals in +-64 m of fixed point; false when the box
+// cannot guarantee |residual| < 64 m for every point (or a point is not finite).
+struct GridBudget {
+    double abs_err = 0.0, rel_err = 0.0;
+    bool separable_ok = true;
+};
+
+static GridBudget grid_budget(const ccal_ctx* ctx, const CloudSet& cs, const double base_pose[6],
+                              const ccal_grid* g, bool separable)
+{
+    GridBudget gb;
+    const int C = cs.n_clouds;
+    const double u24 = 0x1p-24;
+    const double inf = std::numeric_limits<double>::infinity();
+    double theta = 0.0, t2 = 0.0;
+    for (int k = 0; k < 6; ++k) {
+        const double lo = g->min[k], hi = g->min[k] + (g->count[k] - 1) * g->step[k];
+        const double off = std::max(std::fabs(lo), std::fabs(hi));
+        if (k < 3) t2 += (off / 1000.0) * (off / 1000.0);
+        else theta += off * 3.141592 / 180;
+    }
+    const double T = std::sqrt(t2) * (1.0 + 1e-9);
+    theta *= 1.0 + 1e-9;
+    std::vector<double> mats((size_t)C * 12);
+    pose_matrices(cs, base_pose, mats.data());
+    double pl[4];
+    for (int e = 0; e < 4; ++e) pl[e] = (double)ctx->plane[e];
+    const double inv_norm = 1.0 / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+    const double k_dense = ctx->fast_kernel == CCAL_FAST_F32 ? 2.0 + 4.0 : 2.0 + 2.0 * 34.0 + 1.0;
+    double total = 0.0;
+    for (int j = 0; j < C; ++j) {
+        const double* M = mats.data() + 12 * (size_t)j;
+        const double* B = cs.base_T_flange.data() + 16 * (size_t)j;
+        const double* c = cs.centres.data() + 3 * (size_t)j;
+        const double rho = cs.radius_mean[j], rn = cs.rot_norm[j] * (1.0 + 1e-9);
+        const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        const double D = cn * theta + T;
+        double ex = 0.0, w4 = pl[3] * inv_norm, w4_slack = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
+            const double row = std::sqrt(B[r * 4] * B[r * 4] + B[r * 4 + 1] * B[r * 4 + 1] + B[r * 4 + 2] * B[r * 4 + 2]);
+            const double wgt = std::fabs(pl[r]) * inv_norm;
+            ex += wgt * (std::fabs(q) + row * D + rn * rho);
+            w4 += pl[r] * inv_norm * q;
+            w4_slack += wgt * row * D;
+        }
+        const double w4max = std::fabs(w4) + w4_slack;
+        double budget;
+        if (separable) {
+            const double span = 2.0 * rn * T;
+            budget = u24 * ex + u24 * (6.0 * rn * rho + 5.0 * w4max + span) + 0x1p-31;
+            // largest |residual| the histogram pass can meet: rotation part + constant, translation excluded
+            const double vmax = rn * cs.radius[j] + w4max;
+            if (!(vmax < 60.0)) gb.separable_ok = false;
+        } else {
+            budget = u24 * ex + k_dense * u24 * (rn * rho + w4max);
+        }
+        total += budget;
+    }
+    gb.abs_err = std::isfinite(total) ? kScreenSlack * total / (double)C : inf;
+    gb.rel_err = separable ? 2.0 * u24 : kScreenSlack * 133.0 * u24;
+    return gb;
+}
+
 // Fast-path costs of grid candidates [begin, end) into device memory (*cost_local points at
 // candidate `begin`), by the dense kernels or the separable pass as the context says.
 static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_pose[6], const ccal_grid* g,
-                          int64_t begin, int64_t end, float** cost_local, double* kernel_ms, int* launches)
+                          int64_t begin, int64_t end, float** cost_local, double* kernel_ms, int* launches,
+                          GridBudget* budget)
 {
     const int64_t n_local = end - begin;
     *kernel_ms = 0.0;
     *launches = 0;
     // the separable pass keeps 2^-32 m fixed-point sums of up to 64 m per point in 64 bits:
-    // clouds of 2^25 points or more take the dense sweep
+    // clouds of 2^25 points or more, and scenes whose residuals are not certain to stay inside
+    // +-64 m over the whole grid box, take the dense sweep
     bool separable = ctx->search_mode == CCAL_SEARCH_SEPARABLE;
     for (size_t n : cs.n_pts) separable = separable && n < ((size_t)1 << 25);
+    if (separable) {
+        *budget = grid_budget(ctx, cs, base_pose, g, true);
+        separable = budget->separable_ok;
+    }
+    if (!separable) *budget = grid_budget(ctx, cs, base_pose, g, false);
     if (separable) {
         const int64_t rot_count = (int64_t)g->count[3] * g->count[4] * g->count[5];
         const int64_t t0 = begin / rot_count, t1 = (end + rot_count - 1) / rot_count;
@@ -1206,12 +1301,32 @@ extern "C" int ccal_grid_costs(ccal_ctx* ctx, int which, const double base_pose[
     float* cost_local = nullptr;
     double kernel_ms = 0.0;
     int launches = 0;
+    GridBudget budget;
     if (int rc = grid_fast_pass(ctx, ctx->sets[which], base_pose, g, begin, end, &cost_local, &kernel_ms,
-                                &launches))
+                                &launches, &budget))
         return rc;
     CCAL_HIP(ctx, hipMemcpyAsync(cost_out, cost_local, (size_t)(end - begin) * sizeof(float),
                                  hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+extern "C" int ccal_grid_error_bound(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
+                                     double* abs_out, double* rel_out)
+{
+    if (int rc = check_grid_call(ctx, which, base_pose, g, 0, 0, "grid_error_bound")) return rc;
+    if (!abs_out || !rel_out) return fail(ctx, CCAL_ERR_ARG, "grid_error_bound: null argument");
+    const CloudSet& cs = ctx->sets[which];
+    bool separable = ctx->search_mode == CCAL_SEARCH_SEPARABLE;
+    for (size_t n : cs.n_pts) separable = separable && n < ((size_t)1 << 25);
+    GridBudget b;
+    if (separable) {
+        b = grid_budget(ctx, cs, base_pose, g, true);
+        separable = b.separable_ok;
+    }
+    if (!separable) b = grid_budget(ctx, cs, base_pose, g, false);
+    *abs_out = b.abs_err;
+    *rel_out = b.rel_err;
     return CCAL_OK;
 }
 
@@ -1239,69 +1354,95 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     float* cost_local = nullptr;
     double kernel_ms = 0.0;
     int launches = 0;
-    if (int rc = grid_fast_pass(ctx, cs, base_pose, g, begin, end, &cost_local, &kernel_ms, &launches))
+    GridBudget budget;
+    if (int rc = grid_fast_pass(ctx, cs, base_pose, g, begin, end, &cost_local, &kernel_ms, &launches, &budget))
         return rc;
 
-    // arg-min and near-minimum band over the local cost array
+    // arg-min of the fast costs, then every candidate the error budget cannot exclude:
+    //   fast(c) (1 - rel) <= fast_min (1 + rel) + 2 abs
     const int n_stage1 = (int)std::min<int64_t>(1024, (n_local + 255) / 256);
     CCAL_HIP(ctx, ctx->minrec_buf.ensure((size_t)(n_stage1 + 1) * sizeof(MinRec)));
     CCAL_HIP(ctx, ctx->list_buf.ensure((size_t)kBandCap * sizeof(int64_t)));
     CCAL_HIP(ctx, ctx->count_buf.ensure(sizeof(unsigned int)));
     MinRec* recs = ctx->minrec_buf.as<MinRec>();
-    CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, sizeof(unsigned int), ctx->stream));
+    const double band_rel = budget.rel_err, band_abs = 2.0 * budget.abs_err;
+    auto select = [&](int64_t w0, int64_t wn, unsigned int* n_out) -> int {
+        CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, sizeof(unsigned int), ctx->stream));
+        const int blocks = (int)std::min<int64_t>(1024, (wn + 255) / 256);
+        hipLaunchKernelGGL(select_band_kernel, dim3(blocks), dim3(256), 0, ctx->stream, cost_local + w0, wn, w0,
+                           recs + n_stage1, band_rel, band_abs, ctx->list_buf.as<int64_t>(), kBandCap,
+                           ctx->count_buf.as<unsigned int>());
+        CCAL_HIP(ctx, hipGetLastError());
+        CCAL_HIP(ctx, hipMemcpyAsync(n_out, ctx->count_buf.p, sizeof *n_out, hipMemcpyDeviceToHost, ctx->stream));
+        return CCAL_OK;
+    };
     hipLaunchKernelGGL(argmin_stage1_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
                        cost_local, n_local, recs);
     hipLaunchKernelGGL(argmin_stage2_kernel, dim3(1), dim3(256), 0, ctx->stream, recs, n_stage1,
                        recs + n_stage1);
-    hipLaunchKernelGGL(select_band_kernel, dim3(n_stage1), dim3(256), 0, ctx->stream,
-                       cost_local, n_local, recs + n_stage1, kBand,
-                       ctx->list_buf.as<int64_t>(), kBandCap, ctx->count_buf.as<unsigned int>());
-    CCAL_HIP(ctx, hipGetLastError());
+    unsigned int n_band = 0;
+    if (int rc = select(0, n_local, &n_band)) return rc;
     CCAL_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
 
-    MinRec mn;
-    unsigned int n_band = 0;
-    CCAL_HIP(ctx, hipMemcpyAsync(&mn, recs + n_stage1, sizeof mn, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    CCAL_HIP(ctx, hipMemcpyAsync(&n_band, ctx->count_buf.p, sizeof n_band, hipMemcpyDeviceToHost,
-                                 ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float total_ms = 0.f;
     (void)hipEventElapsedTime(&total_ms, ev_begin, ev_end);
 
-    if (!(mn.cost < std::numeric_limits<float>::infinity()) || mn.index < 0)
-        return fail(ctx, CCAL_ERR_DEVICE, "grid_search: non-finite costs on the fast path");
-    if (n_band > kBandCap)
-        return fail(ctx, CCAL_ERR_CAPACITY,
-                    "grid_search: more near-minimum candidates than the re-score list holds");
-    std::vector<int64_t> list(n_band);
-    CCAL_HIP(ctx, hipMemcpy(list.data(), ctx->list_buf.p, (size_t)n_band * sizeof(int64_t),
-                            hipMemcpyDeviceToHost));
-    std::sort(list.begin(), list.end());
-
-    // re-score the band with the reference arithmetic; strict '<' in index order
-    std::vector<double> poses((size_t)n_band * 6), exact(n_band);
-    for (unsigned i = 0; i < n_band; ++i)
-        ccal_grid_pose(g, base_pose, begin + list[i], poses.data() + 6 * (size_t)i);
-    if (int rc = ccal::eval_exact(ctx, which, (int)n_band, poses.data(), nullptr, exact.data(),
-                                  nullptr, nullptr))
-        return rc;
+    // (Non-finite fast costs are kept by the selection -- the comparison that drops a candidate is
+    // false for them -- and the reference arithmetic decides: a NaN or infinite cost never passes
+    // the strict '<' against 1e9, so a set that yields nothing else returns index -1.)
+    // re-score with the reference arithmetic; strict '<' in index order (:542)
     double error_min = 1e9;
-    int64_t best = -1;
-    for (unsigned i = 0; i < n_band; ++i)
-        if (exact[i] < error_min) { error_min = exact[i]; best = (int64_t)i; }
+    int64_t best = -1, n_rescored = 0;
+    std::vector<int64_t> list;
+    std::vector<double> poses, exact;
+    auto rescore = [&](unsigned int n) -> int {
+        list.resize(n);
+        CCAL_HIP(ctx, hipMemcpy(list.data(), ctx->list_buf.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        std::sort(list.begin(), list.end());
+        poses.resize((size_t)n * 6);
+        exact.resize(n);
+        for (unsigned i = 0; i < n; ++i) ccal_grid_pose(g, base_pose, begin + list[i], poses.data() + 6 * (size_t)i);
+        if (int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), nullptr, exact.data(), nullptr, nullptr))
+            return rc;
+        for (unsigned i = 0; i < n; ++i)
+            if (exact[i] < error_min) {
+                error_min = exact[i];
+                best = list[i];
+                std::memcpy(best_pose, poses.data() + 6 * (size_t)i, 6 * sizeof(double));
+            }
+        n_rescored += n;
+        return CCAL_OK;
+    };
+    if (n_band <= kBandCap) {
+        if (int rc = rescore(n_band)) return rc;
+    } else {
+        // more near-minimum candidates than one list holds (flat or repeated grids, an infinite
+        // budget): the range is walked in windows no longer than the list, in index order
+        for (int64_t w0 = 0; w0 < n_local; w0 += kBandCap) {
+            const int64_t wn = std::min<int64_t>(kBandCap, n_local - w0);
+            unsigned int n_win = 0;
+            if (int rc = select(w0, wn, &n_win)) return rc;
+            CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_win == 0) continue;
+            if (int rc = rescore(n_win)) return rc;
+        }
+    }
     if (best >= 0) {
-        *best_index = begin + list[best];
+        *best_index = begin + best;
         *best_cost = error_min;
-        std::memcpy(best_pose, poses.data() + 6 * (size_t)best, 6 * sizeof(double));
+    } else {
+        std::memcpy(best_pose, base_pose, 6 * sizeof(double));
     }
     if (stats) {
         stats->n_candidates = n_local;
-        stats->n_rescored = n_band;
+        stats->n_rescored = n_rescored;
         stats->residuals = (double)n_local * (double)cs.total_pts;
         stats->kernel_ms = kernel_ms;
         stats->kernel_launches = launches;
         stats->total_ms = total_ms;
+        stats->band_abs = budget.abs_err;
+        stats->band_rel = budget.rel_err;
     }
     return CCAL_OK;
 }
@@ -1330,6 +1471,24 @@ static bool solve3(long double A[3][4], long double x[3])
         x[r] = s / A[r][r];
     }
     return true;
+}
+
+// Normal equations of [x y 1](a b c')^T = -z about the origin `org`, from the ten moments.
+static int plane_from_moments(ccal_ctx* ctx, const double* m, const double org[3], float plane_out[4], const char* who)
+{
+    long double A[3][4] = {{m[4], m[5], m[1], -m[7]},
+                           {m[5], m[6], m[2], -m[8]},
+                           {m[1], m[2], m[0], -m[3]}};
+    long double p[3];
+    if (!solve3(A, p)) return fail(ctx, CCAL_ERR_ARG, std::string(who) + ": degenerate point set");
+    const double a = (double)p[0], b = (double)p[1];
+    const double c = (double)(p[2] - p[0] * org[0] - p[1] * org[1] - (long double)org[2]);
+    const double len = std::sqrt(a * a + b * b + 1.0);
+    plane_out[0] = (float)(a / len);
+    plane_out[1] = (float)(b / len);
+    plane_out[2] = (float)(1.0 / len);
+    plane_out[3] = (float)(c / len);
+    return CCAL_OK;
 }
 
 extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6],
@@ -1362,20 +1521,7 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     double m[kMoments];
     CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // normal equations of [x y 1](a b c')^T = -z about the origin `org`
-    long double A[3][4] = {{m[4], m[5], m[1], -m[7]},
-                           {m[5], m[6], m[2], -m[8]},
-                           {m[1], m[2], m[0], -m[3]}};
-    long double p[3];
-    if (!solve3(A, p)) return fail(ctx, CCAL_ERR_ARG, "fit_plane_lsq: degenerate point set");
-    const double a = (double)p[0], b = (double)p[1];
-    const double c = (double)(p[2] - p[0] * org[0] - p[1] * org[1] - (long double)org[2]);
-    const double len = std::sqrt(a * a + b * b + 1.0);
-    plane_out[0] = (float)(a / len);
-    plane_out[1] = (float)(b / len);
-    plane_out[2] = (float)(1.0 / len);
-    plane_out[3] = (float)(c / len);
-    return CCAL_OK;
+    return plane_from_moments(ctx, m, org, plane_out, "fit_plane_lsq");
 }
 
 #include "ransac_impl.hpp"

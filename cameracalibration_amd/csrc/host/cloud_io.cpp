@@ -297,12 +297,12 @@ Cloud read_point_cloud(const std::string& filename, const std::string& metric)
     return c;
 }
 
-Cloud filter_z(const Cloud& in, float z_max)
+Cloud filter_z(const Cloud& in, double z_max)
 {
     Cloud out;
     out.reserve(in.size());
     for (size_t i = 0; i + 2 < in.size(); i += 3)
-        if (in[i + 2] <= z_max) out.insert(out.end(), in.begin() + i, in.begin() + i + 3);
+        if ((double)in[i + 2] <= z_max) out.insert(out.end(), in.begin() + i, in.begin() + i + 3);
     return out;
 }
 

@@ -28,8 +28,10 @@ Cloud read_ply(const std::string& filename);
 Cloud read_pcd(const std::string& filename);
 Cloud read_xyz_text(const std::string& filename, double scale);
 
-// keeps points with z <= z_max (NaN z is dropped, as `pts.z<=0.8` does)
-Cloud filter_z(const Cloud& in, float z_max);
+// keeps points with z <= z_max (NaN z is dropped, as `pts.z<=0.8` does).  The comparison is in
+// double as in the reference, where the float z is promoted against the literal 0.8: a point
+// with z == 0.8f (0.800000011920929, e.g. 800 mm read with the mm metric) is dropped.
+Cloud filter_z(const Cloud& in, double z_max);
 
 // Deterministic voxel-grid centroid filter: PCL's index arithmetic (float
 // inverse leaf, floor(p*inv) - min_b, x-fastest linear index), voxels emitted in

@@ -85,7 +85,7 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
         auto work = [&]() {
             for (size_t k = next++; k < filenames.size(); k = next++) {
                 try {
-                    Cloud kept = filter_z(read_point_cloud(filenames[k], camera_metric), 0.8f);
+                    Cloud kept = filter_z(read_point_cloud(filenames[k], camera_metric), 0.8);
                     if (kept.empty()) throw std::runtime_error(filenames[k] + ": no points with z <= 0.8");
                     in.raw[k] = std::move(kept);
                 } catch (...) {
@@ -370,6 +370,24 @@ extern "C" int ccal_voxel_grid(const float* xyz, size_t n, float leaf, float* xy
     std::memcpy(xyz_out, out.data(), out.size() * sizeof(float));
     *n_out = out.size() / 3;
     return CCAL_OK;
+}
+
+extern "C" int ccal_filter_z(const float* xyz, size_t n, double z_max, float* xyz_out, size_t* n_out)
+{
+    if ((!xyz && n) || !xyz_out || !n_out) return CCAL_ERR_ARG;
+    const Cloud kept = filter_z(Cloud(xyz, xyz + 3 * n), z_max);   // the routine the run itself uses
+    std::memcpy(xyz_out, kept.data(), kept.size() * sizeof(float));
+    *n_out = kept.size() / 3;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_parse_pose(const char* value_csv, const char* metric, const char* angle, double pose[6])
+{
+    if (!value_csv || !pose) return CCAL_ERR_ARG;
+    for (int k = 0; k < 6; ++k) pose[k] = 0.0;
+    const std::string a = angle ? angle : "radian";
+    const int n = parse_pose_csv(value_csv, metric_scale(metric ? metric : "m"), a == "degree", pose);
+    return n == 6 ? CCAL_OK : CCAL_ERR_IO;
 }
 
 extern "C" void ccal_free(void* p) { std::free(p); }

@@ -879,21 +879,23 @@ __global__ __launch_bounds__(256) void argmin_stage2_kernel(const MinRec* __rest
     if (threadIdx.x == 0) { out->cost = c; out->index = i; }
 }
 
-// Appends every candidate with cost <= min*(1+band) to `list` (order arbitrary;
-// the host sorts).  count may exceed cap: entries past cap are dropped and the
-// host reports the overflow.
+// Appends k0 + k for every k in [0, n) with cost[k] (1 - rel) <= min (1 + rel) + abs to `list`
+// (order arbitrary; the host sorts).  count may exceed cap: entries past cap are dropped and the
+// host walks the range in windows instead.
 __global__ __launch_bounds__(256) void select_band_kernel(const float* __restrict__ cost,
-                                                          int64_t n, const MinRec* __restrict__ mn,
-                                                          float band, int64_t* __restrict__ list,
+                                                          int64_t n, int64_t k0, const MinRec* __restrict__ mn,
+                                                          double rel, double abs_band, int64_t* __restrict__ list,
                                                           unsigned int cap,
                                                           unsigned int* __restrict__ count)
 {
-    const float limit = mn->cost * (1.0f + band);
+    // rounded up: a candidate on the edge is kept
+    const double limit = ((double)mn->cost * (1.0 + rel) + abs_band) * (1.0 + 0x1p-40);
+    const double keep = 1.0 - rel;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
          k += (int64_t)gridDim.x * blockDim.x) {
-        if (cost[k] <= limit) {
+        if (!((double)cost[k] * keep > limit)) {
             unsigned int slot = atomicAdd(count, 1u);
-            if (slot < cap) list[slot] = k;
+            if (slot < cap) list[slot] = k0 + k;
         }
     }
 }

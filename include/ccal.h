@@ -176,13 +176,21 @@ typedef struct {
     double  kernel_ms;      /* HIP-event time of the residual kernels, summed */
     int     kernel_launches;
     double  total_ms;       /* HIP-event time of the whole call's device work */
+    double  band_abs;       /* the error budget the re-score set was chosen with:            */
+    double  band_rel;       /* |fast - ccal_eval cost| <= band_abs + band_rel * fast         */
 } ccal_grid_stats;
 
 /* Arg-min of the objective over grid candidates [begin,end) on this GPU.
  * Replaces the 6-deep loop nest :533-548.  The winner is the lowest-index
- * minimum of the reference-arithmetic cost (strict '<', :542): every candidate
- * whose fast-path cost is within a relative band of the fast-path minimum is
- * re-scored with ccal_eval arithmetic before the final comparison.
+ * minimum of the reference-arithmetic cost (strict '<', :542).  The fast path
+ * comes with a bound on its distance from the ccal_eval cost that holds for
+ * every candidate of the grid (ccal_grid_error_bound); every candidate that the
+ * bound cannot exclude -- fast (1 - rel) <= fast_min (1 + rel) + 2 abs -- is
+ * re-scored with ccal_eval arithmetic before the final comparison, in passes of
+ * 65536 when there are many (flat grids, scenes with points on the plane), so
+ * the call never fails for the number of near-ties.  A NaN cost never wins
+ * (:542 is false for it); a set holding non-finite points makes the bound
+ * infinite and every candidate is re-scored.
  * Shards of one grid (one per GPU) are merged with ccal_argmin_merge or an
  * all-gather of (cost,index) pairs.  stats may be NULL. */
 int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
@@ -196,6 +204,15 @@ int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
  * :541-547; this exposes the whole sweep for inspection and tests. */
 int ccal_grid_costs(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
                     int64_t begin, int64_t end, float* cost_out);
+
+/* The bound ccal_grid_search works with, for the current search mode and fast kernel: for
+ * every candidate c of the grid, |ccal_grid_costs value of c - ccal_eval cost of c| <=
+ * *abs_out + *rel_out * (ccal_grid_costs value of c).  Derived on the host from the cloud
+ * centres and mean radii, the robot matrices, the plane and the extent of the grid box; infinite
+ * when the set holds a non-finite point.  (The reference has one arithmetic and needs no such
+ * bound; this is what makes the index of :542 identical although the sweep runs in FP32.) */
+int ccal_grid_error_bound(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
+                          double* abs_out, double* rel_out);
 
 /* Lexicographic (cost, index) minimum over n shard results; entries with
  * index < 0 (empty shards) are skipped.  Returns the winning slot or -1. */
@@ -280,6 +297,18 @@ int  ccal_read_point_cloud(const char* filename, const char* metric, float** xyz
  * n points; n_out receives the number of centroids. */
 int  ccal_voxel_grid(const float* xyz, size_t n, float leaf, float* xyz_out, size_t* n_out);
 void ccal_free(void* p);
+/* The depth cut of camera_calibration_optimization.cpp:167-169 (`pts.z<=0.8`): keeps the points
+ * with (double)z <= z_max, in order; NaN z is dropped.  xyz_out must hold n points (it may be
+ * xyz itself). */
+int  ccal_filter_z(const float* xyz, size_t n, double z_max, float* xyz_out, size_t* n_out);
+
+/* The pose parser of getTransVector (camera_calibration_optimization.cpp:70-98; the rows of
+ * readTransformations, helpers.cpp:244-251, go through the same routine with angle = radians):
+ * six comma-separated fields read with float precision (std::stof), the first three divided by
+ * 1000 ("mm") or 100 ("cm"); with angle == "degree" the last three go through
+ * degreeToRadian(int) (helpers.hpp:275-278: the value is TRUNCATED to whole degrees and pi is
+ * 3.141592); any other angle string means radians.  CCAL_ERR_IO when fewer than six fields parse. */
+int  ccal_parse_pose(const char* value_csv, const char* metric, const char* angle, double pose[6]);
 
 /* Writes a copy of `config_in` whose approximate_transformation holds `pose` (metres,
  * radians): the "output new config file after running the optimization" item of the

@@ -35,7 +35,7 @@ def main():
     clouds = []
     for i in range(1, 5):
         a = read_ply_xyz(REF + "pointcloud/cloud_%d.ply" % i)
-        clouds.append(a[a[:, 2] <= 0.8])
+        clouds.append(a[a[:, 2].astype(np.float64) <= 0.8])   # float z promoted to double (:168)
     ik_lines = [l for l in open(REF + "BaseToFlange.csv").read().split("\n") if l.strip()]
     B = np.stack([O.pose_to_matrix(O.parse_pose_csv(l)) for l in ik_lines])
     pose = O.parse_pose_csv("0.0204504,0.111258,0.0505291,-3.15376,-0.0280023,1.58043")

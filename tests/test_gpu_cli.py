@@ -36,6 +36,7 @@ def build_case(tmp, ccal):
     for k, cid in enumerate(order):
         pts = s.clouds[k].copy()
         pts[::997, 2] = 0.9                       # dropped by the z <= 0.8 filter
+        pts[5::1009, 2] = np.float32(0.8)         # 0.800000011920929 > 0.8 in double: dropped too (:168)
         if cid == 3:
             path = str(tmp / "pc" / ("cloud_%d.pcd" % cid))
             write_pcd_binary(path, pts)
@@ -87,7 +88,7 @@ def oracle_expected(O, ccal, cfg, files, order, ik, init):
     raw = []
     for f in files:
         a = ccal.read_point_cloud(f)
-        raw.append(a[a[:, 2] <= 0.8])
+        raw.append(a[a[:, 2].astype(np.float64) <= 0.8])     # float z promoted to double (:168)
     ds = [O.voxel_grid(c, 0.02) for c in raw]
     ik_rows = [O.parse_pose_csv(l, scale=1000.0) for l in open(ik).read().split("\n") if l.strip()]
     B = np.stack([O.pose_to_matrix(ik_rows[cid - 1]) for cid in order])

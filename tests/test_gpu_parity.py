@@ -406,6 +406,156 @@ def test_grid_ties_pick_lowest_index(gpu_opt, oracle, ccal):
     assert st.n_rescored >= 4
 
 
+def _grid_all(ccal, g, base):
+    return np.stack([ccal.grid_pose(g, base, i) for i in range(g.size)])
+
+
+@pytest.mark.parametrize("mode,kind", [(0, 0), (0, 1), (0, 2), (1, 0)])
+def test_grid_error_bound_holds(gpu_opt, ccal, mode, kind):
+    """The bound the search selects its re-score set with: |fast - exact| <= abs + rel * fast for every
+    candidate of the box, for each dense kernel and the separable pass, on calibration-like scenes and
+    on scenes over five decades of scale with non-rigid robot matrices; and it stays small enough to be
+    of use (a few 1e-3 of the cost on a calibration-like scene)."""
+    rng = np.random.default_rng(21 + 10 * mode + kind)
+    gpu_opt.set_fast_kernel(kind)
+    gpu_opt.set_search_mode(mode)
+    try:
+        s = make_scene(5, 9000, seed=8, ragged=True)
+        upload(gpu_opt, s)
+        g = ccal.Grid.make([-20] * 3 + [-5] * 3, [8] * 3 + [2] * 3, [6, 6, 6, 6, 6, 6])
+        a, r = gpu_opt.grid_error_bound(s.pose_init, g)
+        fast = gpu_opt.grid_costs(s.pose_init, g).astype(np.float64)
+        exact = np.concatenate([gpu_opt.get_error(p) for p in np.array_split(_grid_all(ccal, g, s.pose_init), 12)])
+        err = np.abs(fast - exact)
+        assert np.all(err <= a + r * fast)
+        assert a + r * exact.min() < 5e-3 * exact.min()
+        _, _, _, st = gpu_opt.grid_search(s.pose_init, g)
+        assert (st.band_abs, st.band_rel) == (a, r) and st.n_rescored < 64
+        for trial in range(12):
+            scale = 10.0 ** rng.uniform(-3, 2)
+            n_clouds = int(rng.integers(1, 5))
+            clouds = [(rng.normal(0, scale, (int(rng.integers(1, 3000)), 3)) + rng.normal(0, 5 * scale, 3)).astype(np.float32)
+                      for _ in range(n_clouds)]
+            B = np.stack([ccal.pose_to_matrix(
+                np.concatenate([rng.normal(0, scale, 3), rng.uniform(-3, 3, 3)])).reshape(16) for _ in range(n_clouds)])
+            if trial % 3 == 0:
+                B[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]] *= 10.0 ** rng.uniform(-1, 1, (n_clouds, 9))
+            gpu_opt.upload_clouds(0, clouds, B)
+            plane = rng.normal(0, 1, 4)
+            plane[3] *= scale
+            gpu_opt.set_plane(plane)
+            base = np.concatenate([rng.normal(0, scale, 3), rng.uniform(-3, 3, 3)])
+            counts = [int(c) for c in rng.integers(1, 5, 6)]
+            g = ccal.Grid.make(list(rng.uniform(-30, 0, 3) * scale) + list(rng.uniform(-8, 0, 3)),
+                               list(rng.uniform(0, 20, 3) * scale) + list(rng.uniform(0, 4, 3)), counts)
+            a, r = gpu_opt.grid_error_bound(base, g)
+            fast = gpu_opt.grid_costs(base, g).astype(np.float64)
+            exact = gpu_opt.get_error(_grid_all(ccal, g, base))
+            assert np.all(np.abs(fast - exact) <= a + r * fast), (trial, scale)
+    finally:
+        gpu_opt.set_fast_kernel(0)
+        gpu_opt.set_search_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_search_points_on_the_plane(gpu_opt, oracle, ccal, mode):
+    """Points exactly on the plane for many candidates (identity robot poses, plane z = 0.25, points with
+    z = 0.25, candidates that move them inside the plane): the reference-arithmetic cost is exactly 0 for
+    all of them while the fast costs are rounding noise around 0, so a band relative to the fast minimum
+    would hold almost nothing.  The lowest index among the exact ties must win (:542)."""
+    rng = np.random.default_rng(3)
+    clouds = [np.column_stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), np.full(n, 0.25)]).astype(np.float32)
+              for n in (700, 1300)]
+    B = np.repeat(np.eye(4).reshape(1, 16), 2, axis=0)
+    gpu_opt.upload_clouds(0, clouds, B)
+    plane = np.float32([0, 0, 1, -0.25])
+    gpu_opt.set_plane(plane)
+    gpu_opt.set_search_mode(mode)
+    try:
+        o = oracle.OracleScene(clouds, B)
+        base = np.zeros(6)
+        mins, steps, counts = [-4, -4, -1, -5, 0, 0], [4, 4, 1, 5, 0, 0], [3, 3, 3, 3, 1, 1]
+        idx, cost, pose, st = gpu_opt.grid_search(base, ccal.Grid.make(mins, steps, counts))
+        oi, oc, op, _ = o.grid_search(plane, base, oracle.make_grid(mins, steps, counts))
+        assert (idx, cost) == (oi, oc) == (3, 0.0) and st.n_rescored >= 27
+        np.testing.assert_array_equal(pose, op)
+        # shards: the tie is resolved inside every shard and across them
+        from cameracalibration_amd.binding import argmin_merge
+        parts = [gpu_opt.grid_search(base, ccal.Grid.make(mins, steps, counts), b, e) for b, e in ((0, 40), (40, 81))]
+        w = argmin_merge([p[1] for p in parts], [p[0] for p in parts])
+        assert parts[w][0] == oi and parts[1][0] == 40
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_search_one_point_clouds(gpu_opt, oracle, ccal, mode):
+    s = make_scene(3, 1, seed=17)
+    upload(gpu_opt, s)
+    gpu_opt.set_search_mode(mode)
+    try:
+        o = oracle.OracleScene(s.clouds, s.base_T_flange)
+        mins, steps, counts = [-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6
+        idx, cost, pose, _ = gpu_opt.grid_search(s.pose_init, ccal.Grid.make(mins, steps, counts))
+        oi, oc, op, _ = o.grid_search(s.plane, s.pose_init, oracle.make_grid(mins, steps, counts))
+        assert (idx, cost) == (oi, oc)
+        np.testing.assert_array_equal(pose, op)
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_search_more_near_ties_than_one_list(gpu_opt, oracle, ccal, mode):
+    """68 921 candidates that all tie (a flat grid, and a grid whose translations move the points inside the
+    plane): more than the 65 536 one re-score list holds.  The search walks them in windows and returns the
+    reference's answer, index 0, instead of failing."""
+    rng = np.random.default_rng(4)
+    clouds = [np.column_stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), rng.normal(0.25, 0.001, n)]).astype(np.float32)
+              for n in (40, 90)]
+    B = np.repeat(np.eye(4).reshape(1, 16), 2, axis=0)
+    gpu_opt.upload_clouds(0, clouds, B)
+    plane = np.float32([0, 0, 1, -0.25])
+    gpu_opt.set_plane(plane)
+    gpu_opt.set_search_mode(mode)
+    try:
+        o = oracle.OracleScene(clouds, B)
+        base = np.array([0.001, 0.002, 0.0005, 0.0, 0.0, 0.0])
+        want = o.get_error(base, plane)
+        for steps in ([0] * 6, [1, 1, 0, 0, 0, 0]):
+            g = ccal.Grid.make([0] * 6, steps, [41, 41, 41, 1, 1, 1])
+            idx, cost, _, st = gpu_opt.grid_search(base, g)
+            assert (idx, cost) == (0, want) and st.n_rescored == 41 ** 3
+        # the same kind of grid at a size the oracle scans
+        mins, steps, counts = [0] * 6, [1, 1, 0, 0, 0, 0], [9, 9, 3, 1, 1, 1]
+        oi, oc, _, _ = o.grid_search(plane, base, oracle.make_grid(mins, steps, counts))
+        idx, cost, _, _ = gpu_opt.grid_search(base, ccal.Grid.make(mins, steps, counts))
+        assert (idx, cost) == (oi, oc) == (0, want)
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
+def test_separable_search_leaves_far_scenes_to_the_dense_sweep(gpu_opt, oracle, ccal):
+    """Signed distances beyond the 64 m the histogram pass keeps in fixed point (a scene in millimetre-like
+    units): the separable mode must not saturate silently; it answers with the oracle's winner."""
+    rng = np.random.default_rng(6)
+    clouds = [(rng.normal(0, 40.0, (n, 3)) * [1, 1, 0.05] + [0, 0, 300.0]).astype(np.float32) for n in (500, 800)]
+    B = np.stack([ccal.pose_to_matrix([5.0, -3.0, 2.0, 0.1, -0.2, 0.05]).reshape(16),
+                  ccal.pose_to_matrix([-4.0, 1.0, 0.5, -0.3, 0.1, 0.2]).reshape(16)])
+    gpu_opt.upload_clouds(0, clouds, B)
+    plane = np.float32([0.05, -0.02, 1.0, -120.0])
+    gpu_opt.set_plane(plane)
+    o = oracle.OracleScene(clouds, B)
+    base = np.array([1.0, 2.0, -1.0, 0.02, -0.01, 0.03])
+    mins, steps, counts = [-2000, -2000, -2000, -4, -4, -4], [2000, 2000, 2000, 4, 4, 4], [3] * 6
+    oi, oc, _, _ = o.grid_search(plane, base, oracle.make_grid(mins, steps, counts))
+    gpu_opt.set_search_mode(1)
+    try:
+        idx, cost, _, _ = gpu_opt.grid_search(base, ccal.Grid.make(mins, steps, counts))
+    finally:
+        gpu_opt.set_search_mode(0)
+    assert (idx, cost) == (oi, oc)
+
+
 def test_fit_plane_matches_oracle(gpu_opt, oracle, calib1):
     sub = [calib1["sub_%d" % i] for i in range(4)]
     gpu_opt.upload_clouds(1, sub, calib1["base_T_flange"])

@@ -129,6 +129,37 @@ def test_voxel_grid_matches_oracle(ccal, oracle, calib1):
     assert ccal.voxel_grid(np.zeros((0, 3), np.float32)).shape == (0, 3)
 
 
+def test_depth_cut_compares_in_double(ccal):
+    """`pts.z<=0.8` (:167-169) promotes the float z to double: 0.8f = 0.800000011920929 is dropped."""
+    z = np.array([0.5, np.float32(0.8), np.nextafter(np.float32(0.8), np.float32(0)), 0.9, np.nan, -1.0, 0.8000001],
+                 dtype=np.float32)
+    pts = np.stack([np.arange(len(z), dtype=np.float32), np.zeros(len(z), np.float32), z], axis=1)
+    got = ccal.filter_z(pts)
+    np.testing.assert_array_equal(got[:, 0], [0, 2, 5])
+    # 800 mm read with the mm metric lands exactly on 0.8f
+    assert np.float32(np.float64(np.float32(800.0)) / 1000.0) == np.float32(0.8)
+    assert ccal.filter_z(np.zeros((0, 3), np.float32)).shape == (0, 3)
+
+
+def test_pose_parser_matches_oracle(ccal, oracle):
+    """The product's getTransVector (:70-98) against the oracle's, degree branch included: std::stof
+    precision, int truncation of degrees (towards zero), pi = 3.141592, metric scaling."""
+    cases = [("0.0204504,0.111258,0.0505291,-3.15376,-0.0280023,1.58043", "m", "rad"),
+             ("20.4504, 111.258, 50.5291, -180.7, -1.6, 90.55", "mm", "degree"),
+             (" 2.04504,11.1258,5.05291,179.999,-0.999,0.5", "cm", "degree"),
+             ("1,2,3,4.9,-4.9,359.2", "m", "degree"),
+             ("1e-3,2e-3,-3e-3,1.5e0,-2.25,3", "m", "radian"),
+             ("1,2,3,4,5,6", "mm", "rad")]
+    for csv, metric, angle in cases:
+        scale = {"m": 1.0, "cm": 100.0, "mm": 1000.0}[metric]
+        want = oracle.parse_pose_csv(csv, scale=scale, degree=(angle == "degree"))
+        np.testing.assert_array_equal(ccal.parse_pose(csv, metric, angle), want)
+    got = ccal.parse_pose("0,0,0,4.9,-4.9,359.2", "m", "degree")
+    np.testing.assert_array_equal(got[3:], [4 * 3.141592 / 180, -4 * 3.141592 / 180, 359 * 3.141592 / 180])
+    with pytest.raises(ccal.CcalError):
+        ccal.parse_pose("1,2,3", "m", "rad")
+
+
 def test_run_config_reports_bad_inputs(ccal, tmp_path):
     res, err = str(tmp_path / "results.txt"), str(tmp_path / "errors.txt")
     with pytest.raises(ccal.CcalError, match="cannot open config"):
