@@ -159,6 +159,7 @@ SIGNATURES = {
     "ccal_grid_error_bound": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), _D, _D]),
     "ccal_argmin_merge": (C.c_int, [C.c_int, _D, _P(C.c_int64)]),
     "ccal_fit_plane_lsq": (C.c_int, [_CTX, C.c_int, _D, _F]),
+    "ccal_fit_plane_lsq_static": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_ransac_plane": (
         C.c_int,
         [_CTX, C.c_int, _D, C.c_int, C.c_float, C.c_uint64, _F, _P(C.c_int64)],
@@ -426,6 +427,13 @@ class Optimizer:
         p = np.ascontiguousarray(pose, dtype=np.float64)
         out = np.empty(4, dtype=np.float32)
         self._check(self._lib.ccal_fit_plane_lsq(self._ctx, which, _dptr(p), out.ctypes.data_as(_F)))
+        return out
+
+    def fit_plane_static(self, pose, which: int = CCAL_RAW) -> np.ndarray:
+        """fit_plane through the entry point that allocates nothing (static device scratch)."""
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        out = np.empty(4, dtype=np.float32)
+        self._check(self._lib.ccal_fit_plane_lsq_static(self._ctx, which, _dptr(p), out.ctypes.data_as(_F)))
         return out
 
     def ransac_plane(self, pose, n_hyp: int, threshold: float, seed: int, which: int = CCAL_RAW):

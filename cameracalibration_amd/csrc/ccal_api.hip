@@ -19,6 +19,18 @@
 
 using namespace ccal;
 
+// Scratch of ccal_fit_plane_lsq_static, the one entry point that allocates nothing: the per-cloud
+// matrices of the pose ([kStaticMaxClouds][12]) followed by the per-block partial moments
+// ([kStaticMaxBlocks][kMoments]).  Every GPU holds its own copy of this array at its own address;
+// host code only ever uses the address hipGetSymbolAddress returned for the context's device
+// (ccal_ctx::static_scratch), never the array's name.  All contexts of one GPU share the copy:
+// calls that overlap on one GPU race.  Nothing in it has to start at zero (a call overwrites
+// every row it reads).
+constexpr int kStaticMaxClouds = 1024;
+constexpr int kStaticMaxBlocks = 32768;     // 4096-point blocks: up to 1.3e8 points
+constexpr size_t kStaticScratchDoubles = (size_t)kStaticMaxClouds * 12 + (size_t)kStaticMaxBlocks * kMoments;
+static __device__ __align__(256) double scratch[kStaticScratchDoubles];   // 2.6 MiB per GPU
+
 namespace {
 
 int fail(ccal_ctx* ctx, int code, const std::string& msg)
@@ -245,6 +257,16 @@ extern "C" int ccal_create(int device_id, ccal_ctx** out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->n_cu = prop.multiProcessorCount;
+    // this device's copy of the static scratch array, and a pinned result slot its last kernel writes
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym ||
+        ctx->static_out.ensure(kMoments * sizeof(double)) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->static_out.release();
+        delete ctx;
+        return CCAL_ERR_DEVICE;
+    }
+    ctx->static_scratch = static_cast<double*>(sym);
     *out = ctx;
     return CCAL_OK;
 }
@@ -270,6 +292,7 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     ctx->screen_w.release();
     ctx->split_maps.release();
     ctx->split_first.release();
+    ctx->static_out.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;
@@ -1522,6 +1545,56 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return plane_from_moments(ctx, m, org, plane_out, "fit_plane_lsq");
+}
+
+// Writes rows 0..2 of base_T_flange_j * F for every cloud from the pose's translation and the sines and
+// cosines the host took (same expressions as the host's pose_matrices: bit-identical matrices).
+__global__ __launch_bounds__(256) void pose_rows_kernel(const double* __restrict__ base, int n_clouds,
+                                                        SinCos3 sc, double tx, double ty, double tz,
+                                                        double* __restrict__ mats)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_clouds) return;
+    double R[9];
+    rotation_zyx(sc.s, sc.c, R);
+    const double t[3] = {tx, ty, tz};
+    double M[12];
+    compose_rows(base + 16 * (int64_t)j, R, t, M);
+    for (int e = 0; e < 12; ++e) mats[(int64_t)j * 12 + e] = M[e];
+}
+
+extern "C" int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double pose[6], float plane_out[4])
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!pose || !plane_out) return fail(ctx, CCAL_ERR_ARG, "fit_plane_lsq_static: null argument");
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+    if (C > kStaticMaxClouds || cs.n_blocks > kStaticMaxBlocks)
+        return fail(ctx, CCAL_ERR_CAPACITY,
+                    "fit_plane_lsq_static: the set exceeds the static scratch (at most 1024 clouds and 32768 "
+                    "blocks of 4096 points); use ccal_fit_plane_lsq");
+    if (int rc = bind(ctx)) return rc;
+    // origin for the moments: the first cloud's centre carried to the base frame (as ccal_fit_plane_lsq)
+    const SinCos3 sc = sincos_of_pose(pose);
+    double R[9], M0[12];
+    rotation_zyx(sc.s, sc.c, R);
+    compose_rows(cs.base_T_flange.data(), R, pose, M0);
+    double org[3];
+    for (int r = 0; r < 3; ++r)
+        org[r] = M0[r * 4 + 0] * cs.centres[0] + M0[r * 4 + 1] * cs.centres[1] + M0[r * 4 + 2] * cs.centres[2] +
+                 M0[r * 4 + 3];
+    double* mats = ctx->static_scratch;                               // this device's copy, never the symbol
+    double* part = ctx->static_scratch + (size_t)kStaticMaxClouds * 12;
+    double* m = ctx->static_out.as<double>();                         // pinned: the last kernel writes it
+    hipLaunchKernelGGL(pose_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, cs.base_dev.as<double>(),
+                       C, sc, pose[0], pose[1], pose[2], mats);
+    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.xs.as<float>(),
+                       cs.ys.as<float>(), cs.zs.as<float>(), cs.blocks.as<BlockDesc>(), mats, org[0], org[1], org[2],
+                       InlierMask{{0, 0, 0, 0, 1}, -1.0}, part);
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, cs.n_blocks, m);
+    CCAL_HIP(ctx, hipGetLastError());
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return plane_from_moments(ctx, m, org, plane_out, "fit_plane_lsq_static");
 }
 
 #include "ransac_impl.hpp"
