@@ -162,7 +162,7 @@ SIGNATURES = {
     "ccal_fit_plane_lsq_static": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_ransac_plane": (
         C.c_int,
-        [_CTX, C.c_int, _D, C.c_int, C.c_float, C.c_uint64, _F, _P(C.c_int64)],
+        [_CTX, C.c_int, _D, C.c_int, C.c_float, C.c_uint64, _F, _P(C.c_int64), _P(C.c_int)],
     ),
     "ccal_gd_default_opts": (None, [_P(GdOptions)]),
     "ccal_gd_minimize": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _P(GdOptions), _P(_GdResultC)]),
@@ -437,16 +437,18 @@ class Optimizer:
         return out
 
     def ransac_plane(self, pose, n_hyp: int, threshold: float, seed: int, which: int = CCAL_RAW):
+        """(plane float32[4], inlier count, index of the winning hypothesis)."""
         p = np.ascontiguousarray(pose, dtype=np.float64)
         out = np.empty(4, dtype=np.float32)
         inl = C.c_int64(0)
+        best = C.c_int(-1)
         self._check(
             self._lib.ccal_ransac_plane(
                 self._ctx, which, _dptr(p), int(n_hyp), float(threshold), int(seed),
-                out.ctypes.data_as(_F), C.byref(inl),
+                out.ctypes.data_as(_F), C.byref(inl), C.byref(best),
             )
         )
-        return out, int(inl.value)
+        return out, int(inl.value), int(best.value)
 
     def gradient_descent(self, x0, opts: Optional[GdOptions] = None,
                          which: int = CCAL_DOWNSAMPLED):

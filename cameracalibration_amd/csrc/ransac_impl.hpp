@@ -64,7 +64,7 @@ constexpr int kRecount = 16;  // hypotheses re-counted exactly per pass
 
 extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6], int n_hyp,
                                  float threshold, uint64_t seed, float plane_out[4],
-                                 int64_t* inliers_out)
+                                 int64_t* inliers_out, int* best_hyp_out)
 {
     if (int rc = check_set(ctx, which)) return rc;
     if (!pose || !plane_out || n_hyp <= 0 || !(threshold > 0.f))
@@ -209,5 +209,6 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
     plane_out[2] = (float)n[2];
     plane_out[3] = (float)d;
     if (inliers_out) *inliers_out = (int64_t)best_cnt;
+    if (best_hyp_out) *best_hyp_out = best_h;
     return CCAL_OK;
 }

@@ -237,11 +237,13 @@ int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double pose[6], fl
  * SACMODEL_PLANE, SAC_RANSAC, distance threshold, optimise coefficients):
  * n_hyp three-point hypotheses drawn with a counter-based generator from
  * `seed`, every hypothesis scored against every point of the set in one batched
- * pass, best hypothesis refitted on its inliers (total least squares).
- * plane_out is (n, d) with |n| = 1 and n.z >= 0. */
+ * pass, best hypothesis (most inliers under the reference-arithmetic distance, lowest
+ * index on ties) refitted on its inliers (total least squares).
+ * plane_out is (n, d) with |n| = 1 and n.z >= 0; inliers_out / best_hyp_out (either may be
+ * NULL) receive the winner's inlier count and its index in [0, n_hyp). */
 int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6], int n_hyp,
                       float threshold, uint64_t seed, float plane_out[4],
-                      int64_t* inliers_out);
+                      int64_t* inliers_out, int* best_hyp_out);
 
 /* Gradient-descent refinement with the reference's gdcpp settings.  Replaces
  * gradientDescent (:411-465) for dim 6 and gradientDescentWithPlane (:466-524)

@@ -591,7 +591,21 @@ int orc_file_id(const char* filename)
  * built) and PCL is not in its tree, so there is nothing to restate line by
  * line: this is the CPU statement of the library's own sampling scheme, scored
  * with the reference's distance arithmetic (:121-124) on q = float(M p).
- * Parity unpinned. */
+ * Parity unpinned.
+ *
+ * What the call at cloud_analyzer.cpp:103-121 would do inside PCL (1.7-1.12, from its published
+ * sources; stated for orientation, none of it can be run here):
+ *   - SACSegmentation defaults the reference leaves untouched: max_iterations 50, probability 0.99;
+ *     RandomSampleConsensus draws 3 distinct indices with rand(), skips collinear samples, counts
+ *     points with |a x + b y + c z + d| < threshold (strict), keeps a model only if its count is
+ *     GREATER than the best so far (first found wins ties), and shrinks the iteration bound from the
+ *     inlier ratio;
+ *   - setOptimizeCoefficients(true): SampleConsensusModelPlane::optimizeModelCoefficients takes the
+ *     centroid and covariance of the winner's inliers, the eigenvector of the smallest eigenvalue as
+ *     the normal, d = -n.centroid.  The inliers are not selected again with the refined plane.
+ * Kept from that: the strict threshold test, first-found wins ties, the covariance refit on the
+ * winner's inliers.  Replaced: rand() and the adaptive iteration count (a fixed number of
+ * hypotheses from a counter-based generator, so that every hypothesis can be scored at once). */
 static uint64_t splitmix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -600,40 +614,49 @@ static uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
-static void jacobi3(double A[3][3], double V[3][3])
+/* Point `g` of the set (clouds back to back) carried to the base frame: float(M_j p), :303. */
+static void ransac_point(const orc_scene* s, const double* M, const int64_t* off, int64_t g, float q[3])
 {
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (A[p][q] == 0.0) continue;
-                double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
-                }
-            }
-    }
+    int j = 0;
+    while (g >= off[j + 1]) ++j;
+    orc_transform_point(M + 16 * j, s->xyz[j] + 3 * (g - off[j]), q);
 }
 
-void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
-                      uint64_t seed, float plane_out[4], int64_t* inliers_out, int* best_hyp_out)
+/* Hypothesis h: indices i_k = splitmix64(seed + 3h + k) mod N, a repeat bumped to the next index;
+ * n = (q1 - q0) x (q2 - q0) normalised with n.z >= 0, d = -n.q0; pl = (a, b, c, d, |n|).
+ * Returns 0 for a (nearly) collinear sample. */
+static int ransac_hypothesis(const orc_scene* s, const double* M, const int64_t* off, uint64_t seed,
+                             int h, double pl[5])
+{
+    int64_t total = off[s->n_clouds];
+    int64_t idx[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t v = (int64_t)(splitmix64(seed + 3ull * (uint64_t)h + (uint64_t)k) % (uint64_t)total);
+        for (int t = 0; t < k; ++t)
+            if (v == idx[t]) { v = (v + 1) % total; t = -1; }
+        idx[k] = v;
+    }
+    double p[3][3];
+    for (int k = 0; k < 3; ++k) {
+        float q[3];
+        ransac_point(s, M, off, idx[k], q);
+        for (int r = 0; r < 3; ++r) p[k][r] = (double)q[r];
+    }
+    double u[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
+    double v[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
+    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(len > 1e-12)) return 0;
+    if (n[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len;
+    pl[0] = n[0]; pl[1] = n[1]; pl[2] = n[2];
+    pl[3] = -(n[0] * p[0][0] + n[1] * p[0][1] + n[2] * p[0][2]);
+    pl[4] = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    return 1;
+}
+
+/* Shared set-up: per-cloud matrices and point offsets (caller frees both). */
+static void ransac_setup(const orc_scene* s, const double pose[6], double** M_out, int64_t** off_out)
 {
     int C = s->n_clouds;
     double* M = (double*)malloc((size_t)C * 16 * sizeof(double));
@@ -643,6 +666,32 @@ void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float
         cloud_matrix(s, j, pose, M + 16 * j);
         off[j + 1] = off[j] + (int64_t)s->n_pts[j];
     }
+    *M_out = M;
+    *off_out = off;
+}
+
+int orc_ransac_hypothesis_plane(const orc_scene* s, const double pose[6], uint64_t seed, int h, double pl[5])
+{
+    double* M;
+    int64_t* off;
+    ransac_setup(s, pose, &M, &off);
+    int ok = ransac_hypothesis(s, M, off, seed, h, pl);
+    free(M); free(off);
+    return ok;
+}
+
+/* Winner among n_hyp hypotheses (most inliers, first found on ties), its inlier count, and the ten
+ * moments (1, x, y, z, xx, xy, yy, xz, yz, zz about `org`) of its inliers for the refit, which the
+ * caller does (oracle.py: numpy's LAPACK eigen-decomposition, so that the refit shares no code and
+ * no algorithm with the library's Jacobi sweeps).  plane_out: the winning HYPOTHESIS (not refitted). */
+void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
+                      uint64_t seed, double plane_out[5], int64_t* inliers_out, int* best_hyp_out,
+                      double moments_out[10], double org_out[3])
+{
+    double* M;
+    int64_t* off;
+    ransac_setup(s, pose, &M, &off);
+    int C = s->n_clouds;
     int64_t total = off[C];
     float* q = (float*)malloc((size_t)total * 3 * sizeof(float));
     for (int j = 0; j < C; ++j)
@@ -653,27 +702,8 @@ void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float
     int64_t best_cnt = -1;
     double best_pl[5] = {0, 0, 0, 0, 1};
     for (int h = 0; h < n_hyp; ++h) {
-        int64_t idx[3];
-        for (int k = 0; k < 3; ++k) {
-            int64_t v = (int64_t)(splitmix64(seed + 3ull * (uint64_t)h + (uint64_t)k) % (uint64_t)total);
-            for (int t = 0; t < k; ++t)
-                if (v == idx[t]) { v = (v + 1) % total; t = -1; }
-            idx[k] = v;
-        }
-        double p[3][3];
-        for (int k = 0; k < 3; ++k)
-            for (int r = 0; r < 3; ++r) p[k][r] = (double)q[3 * idx[k] + r];
-        double u[3] = {p[1][0] - p[0][0], p[1][1] - p[0][1], p[1][2] - p[0][2]};
-        double v[3] = {p[2][0] - p[0][0], p[2][1] - p[0][1], p[2][2] - p[0][2]};
-        double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
-        double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-        if (!(len > 1e-12)) continue;
-        if (n[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-        n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len;
         double pl[5];
-        pl[0] = n[0]; pl[1] = n[1]; pl[2] = n[2];
-        pl[3] = -(n[0] * p[0][0] + n[1] * p[0][1] + n[2] * p[0][2]);
-        pl[4] = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (!ransac_hypothesis(s, M, off, seed, h, pl)) continue;
         int64_t cnt = 0;
         for (int64_t i = 0; i < total; ++i) {
             double num = pl[0] * (double)q[3 * i] + pl[1] * (double)q[3 * i + 1] + pl[2] * (double)q[3 * i + 2] + pl[3];
@@ -681,45 +711,26 @@ void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float
         }
         if (cnt > best_cnt) { best_cnt = cnt; best_h = h; memcpy(best_pl, pl, sizeof pl); }
     }
-    double n[3] = {best_pl[0], best_pl[1], best_pl[2]}, d = best_pl[3];
-    if (best_h >= 0) {
-        /* origin as the library uses: first cloud's centre carried to the base frame */
-        double c0[3] = {0, 0, 0};
-        for (size_t i = 0; i < s->n_pts[0]; ++i)
-            for (int k = 0; k < 3; ++k) c0[k] += s->xyz[0][3 * i + k];
-        for (int k = 0; k < 3; ++k) c0[k] /= (double)s->n_pts[0];
-        double org[3];
-        for (int r = 0; r < 3; ++r)
-            org[r] = M[r * 4 + 0] * c0[0] + M[r * 4 + 1] * c0[1] + M[r * 4 + 2] * c0[2] + M[r * 4 + 3];
-        double m[10] = {0};
+    /* origin of the moments: the first cloud's centre carried to the base frame (any fixed point
+     * near the data keeps the sums well conditioned) */
+    double c0[3] = {0, 0, 0};
+    for (size_t i = 0; i < s->n_pts[0]; ++i)
+        for (int k = 0; k < 3; ++k) c0[k] += s->xyz[0][3 * i + k];
+    for (int k = 0; k < 3; ++k) c0[k] /= (double)s->n_pts[0];
+    for (int r = 0; r < 3; ++r)
+        org_out[r] = M[r * 4 + 0] * c0[0] + M[r * 4 + 1] * c0[1] + M[r * 4 + 2] * c0[2] + M[r * 4 + 3];
+    for (int k = 0; k < 10; ++k) moments_out[k] = 0.0;
+    if (best_h >= 0)
         for (int64_t i = 0; i < total; ++i) {
             double num = best_pl[0] * (double)q[3 * i] + best_pl[1] * (double)q[3 * i + 1] +
                          best_pl[2] * (double)q[3 * i + 2] + best_pl[3];
             if (!(fabs(num) / best_pl[4] < (double)threshold)) continue;
-            double x = (double)q[3 * i] - org[0], y = (double)q[3 * i + 1] - org[1], z = (double)q[3 * i + 2] - org[2];
+            double x = (double)q[3 * i] - org_out[0], y = (double)q[3 * i + 1] - org_out[1], z = (double)q[3 * i + 2] - org_out[2];
+            double* m = moments_out;
             m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
             m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z; m[9] += z * z;
         }
-        if (m[0] >= 3.0) {
-            double N = m[0], cx = m[1] / N, cy = m[2] / N, cz = m[3] / N;
-            double A[3][3] = {{m[4] / N - cx * cx, m[5] / N - cx * cy, m[7] / N - cx * cz},
-                              {m[5] / N - cx * cy, m[6] / N - cy * cy, m[8] / N - cy * cz},
-                              {m[7] / N - cx * cz, m[8] / N - cy * cz, m[9] / N - cz * cz}};
-            double V[3][3];
-            jacobi3(A, V);
-            int k = 0;
-            if (A[1][1] < A[k][k]) k = 1;
-            if (A[2][2] < A[k][k]) k = 2;
-            double e[3] = {V[0][k], V[1][k], V[2][k]};
-            double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-            if (len > 0) {
-                double sgn = e[2] < 0 ? -1.0 : 1.0;
-                for (int i = 0; i < 3; ++i) n[i] = sgn * e[i] / len;
-                d = -(n[0] * (cx + org[0]) + n[1] * (cy + org[1]) + n[2] * (cz + org[2]));
-            }
-        }
-    }
-    plane_out[0] = (float)n[0]; plane_out[1] = (float)n[1]; plane_out[2] = (float)n[2]; plane_out[3] = (float)d;
+    memcpy(plane_out, best_pl, sizeof best_pl);
     if (inliers_out) *inliers_out = best_cnt;
     if (best_hyp_out) *best_hyp_out = best_h;
     free(q); free(off); free(M);

@@ -127,7 +127,15 @@ void orc_gd_minimize(const orc_scene* s, const float plane[4], int dim, const do
  * splitmix64(seed+3h+k), exact-arithmetic inlier count, lowest index on ties,
  * covariance refit).  Not a reference restatement: see ccal_oracle.c. */
 void orc_ransac_plane(const orc_scene* s, const double pose[6], int n_hyp, float threshold,
-                      uint64_t seed, float plane_out[4], int64_t* inliers_out, int* best_hyp_out);
+                      uint64_t seed, double plane_out[5], int64_t* inliers_out, int* best_hyp_out,
+                      double moments_out[10], double org_out[3]);
+/* Plane (a, b, c, d, |n|) of hypothesis h alone; 0 when its sample is collinear. */
+int orc_ransac_hypothesis_plane(const orc_scene* s, const double pose[6], uint64_t seed, int h, double pl[5]);
+/* Inlier counts of the listed hypotheses over every point of the set, the point loop spread over
+ * host threads (counts are integers: the result does not depend on the thread count).
+ * counts_out[k] = -1 for a collinear sample.  (ccal_oracle_omp.c) */
+void orc_ransac_counts(const orc_scene* s, const double pose[6], uint64_t seed, float threshold,
+                       const int* hyp, int n, int64_t* counts_out);
 
 /* Per-point distances / classes: optimiser arithmetic (0, :389-404) or the viewer's
  * plane-mode colouring arithmetic (1, src/algorithms.cpp:379-402). */

@@ -113,8 +113,12 @@ def lib() -> C.CDLL:
         L.orc_gd_minimize.argtypes = [
             C.POINTER(Scene), _F, C.c_int, _D, C.POINTER(GdOpts), C.POINTER(GdResult),
         ]
-        L.orc_ransac_plane.argtypes = [C.POINTER(Scene), _D, C.c_int, C.c_float, C.c_uint64, _F,
-                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_ransac_plane.argtypes = [C.POINTER(Scene), _D, C.c_int, C.c_float, C.c_uint64, _D,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int), _D, _D]
+        L.orc_ransac_hypothesis_plane.restype = C.c_int
+        L.orc_ransac_hypothesis_plane.argtypes = [C.POINTER(Scene), _D, C.c_uint64, C.c_int, _D]
+        L.orc_ransac_counts.argtypes = [C.POINTER(Scene), _D, C.c_uint64, C.c_float, C.POINTER(C.c_int), C.c_int,
+                                        C.POINTER(C.c_int64)]
         L.orc_point_errors.argtypes = [C.POINTER(Scene), _D, _D, C.c_int, _D, C.POINTER(C.c_ubyte)]
         L.orc_parse_pose_csv.restype = C.c_int
         L.orc_parse_pose_csv.argtypes = [C.c_char_p, C.c_double, C.c_int, _D]
@@ -199,13 +203,39 @@ class OracleScene:
         return dist, cls
 
     def ransac_plane(self, pose, n_hyp: int, threshold: float, seed: int):
+        """(plane float32[4], inliers, winning hypothesis).  Sampling and counting in C; the refit on the
+        winner's inliers here with numpy's LAPACK eigen-decomposition (PCL's optimizeModelCoefficients:
+        centroid + eigenvector of the smallest covariance eigenvalue, d = -n.centroid)."""
         p = np.ascontiguousarray(pose, dtype=np.float64)
-        out = np.empty(4, dtype=np.float32)
+        hyp = np.empty(5)
+        m = np.empty(10)
+        org = np.empty(3)
         inl = C.c_int64(0)
         best = C.c_int(-1)
-        lib().orc_ransac_plane(C.byref(self.c), _d(p), int(n_hyp), float(threshold), int(seed), _f(out),
-                               C.byref(inl), C.byref(best))
-        return out, int(inl.value), int(best.value)
+        lib().orc_ransac_plane(C.byref(self.c), _d(p), int(n_hyp), float(threshold), int(seed), _d(hyp),
+                               C.byref(inl), C.byref(best), _d(m), _d(org))
+        n, d = hyp[:3].copy(), hyp[3]
+        if best.value >= 0 and m[0] >= 3:
+            N = m[0]
+            c = m[1:4] / N
+            S = np.array([[m[4], m[5], m[7]], [m[5], m[6], m[8]], [m[7], m[8], m[9]]]) / N - np.outer(c, c)
+            w, V = np.linalg.eigh(S)
+            e = V[:, 0]                                    # eigenvalues ascending
+            e = e / np.linalg.norm(e)
+            if e[2] < 0:
+                e = -e
+            n, d = e, -float(e @ (c + org))
+        return np.concatenate([n, [d]]).astype(np.float32), int(inl.value), int(best.value)
+
+    def ransac_counts(self, pose, seed: int, threshold: float, hyps):
+        """Inlier counts of the listed hypotheses over every point (host threads over points)."""
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        h = np.ascontiguousarray(hyps, dtype=np.int32)
+        out = np.empty(len(h), dtype=np.int64)
+        lib().orc_ransac_counts(C.byref(self.c), _d(p), int(seed), float(threshold),
+                                h.ctypes.data_as(C.POINTER(C.c_int)), len(h),
+                                out.ctypes.data_as(C.POINTER(C.c_int64)))
+        return out
 
     def gd_minimize(self, plane, x0, opts: Optional[GdOpts] = None) -> GdResult:
         pl = np.ascontiguousarray(plane, dtype=np.float32)

@@ -55,6 +55,11 @@ def main():
     _, _, _, costs = sc.grid_search(plane_full, pose, g, 0, first, want_costs=True)
     g5 = O.make_grid([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5] * 6)
     bi, bc, bp, _ = sc.grid_search(plane_full, pose, g5)
+    # the shipped workload (:532-538): all 11^6 candidates, costs by host threads, the winner by the
+    # serial strict-'<' scan over them; the eight lowest costs pin the neighbourhood of the minimum
+    b11, c11, p11, costs11 = sc.grid_search(plane_full, pose, g, omp=True)
+    order = np.lexsort((np.arange(len(costs11)), costs11))[:8]
+    assert order[0] == b11 and costs11[b11] == c11
     gd6 = sc.gd_minimize(plane_full, pose)
     x10 = np.concatenate([np.array(gd6.xval[:6]), plane_full.astype(np.float64)])
     gd10 = sc.gd_minimize(plane_full, x10)
@@ -68,6 +73,9 @@ def main():
         cost_init=np.array(sc.get_error(pose, plane_full)),
         grid_first_costs=costs,
         grid5_best=np.array([bi]), grid5_cost=np.array([bc]), grid5_pose=bp,
+        grid11_best=np.array([b11]), grid11_cost=np.array([c11]), grid11_pose=p11,
+        grid11_low_index=order.astype(np.int64), grid11_low_cost=costs11[order],
+        grid11_cost_sum=np.array([np.sum(costs11)]),
         gd6_x=np.array(gd6.xval[:6]), gd6_f=np.array([gd6.fval]),
         gd6_it=np.array([gd6.iterations, gd6.converged, gd6.n_evals]),
         gd10_x=np.array(gd10.xval[:10]), gd10_f=np.array([gd10.fval]),

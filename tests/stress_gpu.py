@@ -237,9 +237,9 @@ def check_ingest(opt, rng, stats):
         print("MISMATCH fit_plane", s.n_points, got, want, flush=True)
     if s.n_points >= 40:
         n_hyp, seed, thr = int(rng.choice([16, 100, 700])), int(rng.integers(1 << 30)), float(rng.choice([0.001, 0.004]))
-        want, want_inl, _ = o.ransac_plane(pose, n_hyp, thr, seed)
-        got, got_inl = opt.ransac_plane(pose, n_hyp, thr, seed, which=1)
-        if got_inl != want_inl or not np.allclose(got, want, rtol=0, atol=5e-7):
+        want, want_inl, want_h = o.ransac_plane(pose, n_hyp, thr, seed)
+        got, got_inl, got_h = opt.ransac_plane(pose, n_hyp, thr, seed, which=1)
+        if (got_inl, got_h) != (want_inl, want_h) or not np.allclose(got, want, rtol=0, atol=5e-7):
             stats["bad"] += 1
             print("MISMATCH ransac", s.n_points, n_hyp, thr, seed, got, want, got_inl, want_inl, flush=True)
 

@@ -97,12 +97,23 @@ def test_full_size_exact_objective_spot_checks(gpu_opt, oracle, big):
     np.testing.assert_array_equal(mx, omx)
 
 
-def test_c3_size_search_and_objective(gpu_opt, ccal, oracle):
+@pytest.fixture(scope="module")
+def huge():
+    """100 clouds x 10^6 points (1.2 GB of coordinates), shared by the C3, C4 and C5 cases."""
+    return make_scene(100, 1_000_000)
+
+
+def grid_of(ccal, counts):
+    return ccal.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (c - 1) for c in counts[:3]] + [10.0 / (c - 1) for c in counts[3:]],
+                          counts)
+
+
+def test_c3_size_search_and_objective(gpu_opt, ccal, oracle, huge):
     """100 clouds x 10^6 points, (20,20,25 | 10,10,10) = 10^7 candidates: the whole grid by the
     separable pass, a cut of it by the dense kernel, shards merged, and one oracle evaluation of
     the winner over all 10^8 points (bit-equal)."""
     from cameracalibration_amd.binding import argmin_merge
-    s = make_scene(100, 1_000_000)
+    s = huge
     gpu_opt.upload_clouds(0, s.clouds, s.base_T_flange)
     gpu_opt.set_plane(s.plane)
     counts = [20, 20, 25, 10, 10, 10]
@@ -130,3 +141,90 @@ def test_c3_size_search_and_objective(gpu_opt, ccal, oracle):
     assert got == cost == o.get_error(pose, s.plane)
     np.testing.assert_array_equal(mean, omean)
     np.testing.assert_array_equal(mx, omx)
+
+
+def test_c4_size_search(gpu_opt, ccal, oracle, huge):
+    """100 clouds x 10^6 points, (20,20,25 | 20,20,25) = 10^8 candidates (10^16 residuals): the whole grid by
+    the separable pass, the same grid as two shards merged, and a dense cut of 10^5 candidates around the
+    winner -- all three must name the same candidate with the same reference-arithmetic cost -- plus one
+    oracle evaluation of the winner over all 10^8 points (bit-equal)."""
+    from cameracalibration_amd.binding import argmin_merge
+    s = huge
+    gpu_opt.upload_clouds(0, s.clouds, s.base_T_flange)
+    gpu_opt.set_plane(s.plane)
+    g = grid_of(ccal, [20, 20, 25, 20, 20, 25])
+    assert g.size == 10 ** 8
+    gpu_opt.set_search_mode(1)
+    try:
+        idx, cost, pose, st = gpu_opt.grid_search(s.pose_init, g)
+        cut = 43_210_000                                         # inside a translation row
+        halves = [gpu_opt.grid_search(s.pose_init, g, 0, cut), gpu_opt.grid_search(s.pose_init, g, cut, 10 ** 8)]
+    finally:
+        gpu_opt.set_search_mode(0)
+    assert st.n_candidates == 10 ** 8 and st.residuals == 1e16 and st.n_rescored >= 1
+    w = argmin_merge([h[1] for h in halves], [h[0] for h in halves])
+    assert (halves[w][0], halves[w][1]) == (idx, cost)
+    assert np.linalg.norm(pose[:3] - s.pose_true[:3]) < np.linalg.norm(s.pose_init[:3] - s.pose_true[:3])
+    b = min(max(0, idx - 50_000), 10 ** 8 - 100_000)
+    idx_d, cost_d, pose_d, _ = gpu_opt.grid_search(s.pose_init, g, b, b + 100_000)
+    assert (idx_d, cost_d) == (idx, cost)
+    np.testing.assert_array_equal(pose_d, pose)
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    assert cost == o.get_error(pose, s.plane)
+    # no axis neighbour of the winner is better (reference arithmetic), equal ones have a higher index
+    counts = [g.count[k] for k in range(6)]
+    strides = [int(np.prod(counts[k + 1:])) for k in range(6)]
+    digits = [(idx // strides[k]) % counts[k] for k in range(6)]
+    nb = [idx + d * strides[k] for k in range(6) for d in (-1, 1) if 0 <= digits[k] + d < counts[k]]
+    nb_cost = gpu_opt.get_error(np.stack([ccal.grid_pose(g, s.pose_init, i) for i in nb]))
+    assert all(c > cost or (c == cost and i > idx) for c, i in zip(nb_cost, nb))
+
+
+def test_c5_size_ransac_and_multi_start_descent(gpu_opt, ccal, oracle, huge):
+    """RANSAC with 4096 hypotheses over 10^8 points on a scene whose noise (4 mm) and outliers (20 % of the
+    points, 2-20 cm off the plane) are comparable to the 0.01 m threshold, so that hypotheses differ in
+    their counts; then 64 lock-step descents.  At this size the oracle cannot score 4096 hypotheses, so:
+    the winner's inlier count is re-counted by the oracle over all 10^8 points; a sample of other hypotheses
+    is counted by the oracle and none beats the winner; with 8 hypotheses the whole call is the oracle's;
+    and three of the 64 descents equal their single-start runs bit for bit."""
+    rng = np.random.default_rng(55)
+    noisy = []
+    for c in huge.clouds:
+        c = c.copy()
+        r = np.linalg.norm(c, axis=1, keepdims=True)
+        c += (c / r) * rng.normal(0.0, 0.004, (len(c), 1)).astype(np.float32)      # along the ray
+        k = len(c) // 5
+        sel = rng.choice(len(c), k, replace=False)
+        c[sel] += (c[sel] / r[sel]) * rng.uniform(0.02, 0.2, (k, 1)).astype(np.float32)
+        noisy.append(c)
+    B, pose = huge.base_T_flange, huge.pose_true
+    gpu_opt.upload_clouds(1, noisy, B)
+    o = oracle.OracleScene(noisy, B)
+    thr, seed = 0.01, 20251111
+    plane, inl, win = gpu_opt.ransac_plane(pose, 4096, thr, seed, which=1)
+    assert 0 <= win < 4096 and 0.5e8 < inl <= 0.8e8              # 80 % of the points, most of them within 2.5 sigma
+    np.testing.assert_allclose(plane, huge.plane, atol=2e-3)
+    sample = [win] + [int(h) for h in rng.choice(4096, 23, replace=False)]
+    counts = o.ransac_counts(pose, seed, thr, sample)
+    assert counts[0] == inl                                      # the winner's count, by the oracle
+    assert all(c < inl or (c == inl and h >= win) for c, h in zip(counts[1:], sample[1:]))
+    assert len(set(counts.tolist())) > 12                        # the hypotheses do not tie on this scene
+    want, want_inl, want_h = o.ransac_plane(pose, 8, thr, seed)
+    got, got_inl, got_h = gpu_opt.ransac_plane(pose, 8, thr, seed, which=1)
+    assert (got_inl, got_h) == (want_inl, want_h)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+
+    gpu_opt.upload_clouds(0, huge.clouds, B)
+    gpu_opt.set_plane(huge.plane)
+    starts = huge.pose_true + rng.uniform(-1, 1, (64, 6)) * np.array([0.02] * 3 + [np.deg2rad(5)] * 3)
+    opts = ccal.GdOptions.default()
+    opts.max_iterations = 3
+    multi = gpu_opt.gradient_descent(starts, opts)
+    assert len(multi) == 64
+    for k in (0, 17, 63):
+        one = gpu_opt.gradient_descent(starts[k], opts)
+        assert (one.iterations, one.converged, one.fval, one.n_evals) == \
+               (multi[k].iterations, multi[k].converged, multi[k].fval, multi[k].n_evals)
+        np.testing.assert_array_equal(one.xval, multi[k].xval)
+    best = min(range(64), key=lambda i: (multi[i].fval, i))
+    assert multi[best].fval < gpu_opt.get_error(starts[best])[0]

@@ -381,6 +381,33 @@ def test_grid_search_calib1_golden_and_shards(gpu_opt, ccal, calib1):
     assert res[1][0] == -1
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_grid_search_calib1_shipped_grid(gpu_opt, ccal, calib1, mode):
+    """The shipped workload: all 11^6 candidates of :532-538 on the example/calib_1 clouds.  Index, cost and
+    pose of the winner are the oracle's full scan (tests/golden/make_golden.py), by the dense sweep and by the
+    separable pass, whole and in three shards; the eight lowest costs of the scan are reproduced bit for bit."""
+    from cameracalibration_amd.binding import argmin_merge
+    ds = [calib1["ds_%d" % i] for i in range(4)]
+    gpu_opt.upload_clouds(0, ds, calib1["base_T_flange"])
+    gpu_opt.set_plane(calib1["plane_full"])
+    gpu_opt.set_search_mode(mode)
+    try:
+        g = ccal.Grid.default()
+        assert g.size == 11 ** 6
+        idx, cost, pose, st = gpu_opt.grid_search(calib1["pose_init"], g)
+        assert idx == int(calib1["grid11_best"][0]) and cost == float(calib1["grid11_cost"][0])
+        np.testing.assert_array_equal(pose, calib1["grid11_pose"])
+        assert st.n_candidates == 11 ** 6 and 1 <= st.n_rescored < 4096
+        cuts = [0, 590_520, 1_181_041, 11 ** 6]
+        parts = [gpu_opt.grid_search(calib1["pose_init"], g, cuts[i], cuts[i + 1]) for i in range(3)]
+        w = argmin_merge([p[1] for p in parts], [p[0] for p in parts])
+        assert (parts[w][0], parts[w][1]) == (idx, cost)
+    finally:
+        gpu_opt.set_search_mode(0)
+    low = np.stack([ccal.grid_pose(g, calib1["pose_init"], int(i)) for i in calib1["grid11_low_index"]])
+    np.testing.assert_array_equal(gpu_opt.get_error(low), calib1["grid11_low_cost"])
+
+
 def test_grid_first_costs_calib1_fast_vs_golden(gpu_opt, ccal, calib1):
     ds = [calib1["ds_%d" % i] for i in range(4)]
     gpu_opt.upload_clouds(0, ds, calib1["base_T_flange"])
@@ -584,10 +611,11 @@ def test_ransac_plane_matches_oracle(gpu_opt, oracle, outliers):
     gpu_opt.upload_clouds(1, clouds, s.base_T_flange)
     o = oracle.OracleScene(clouds, s.base_T_flange)
     for n_hyp, seed in ((64, 1), (500, 12345)):
-        want, want_inl, _ = o.ransac_plane(s.pose_true, n_hyp, 0.004, seed)
-        got, got_inl = gpu_opt.ransac_plane(s.pose_true, n_hyp, 0.004, seed, which=1)
-        assert got_inl == want_inl                       # integer count: identical
-        # same winner, same inlier set; refit moments summed in a different order
+        want, want_inl, want_h = o.ransac_plane(s.pose_true, n_hyp, 0.004, seed)
+        got, got_inl, got_h = gpu_opt.ransac_plane(s.pose_true, n_hyp, 0.004, seed, which=1)
+        assert (got_inl, got_h) == (want_inl, want_h)    # integer count and winner: identical
+        # same inlier set; moments summed in a different order, and the refit by a different
+        # eigen-solver (Jacobi sweeps here, LAPACK in the oracle)
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
         assert abs(np.linalg.norm(got[:3]) - 1) < 1e-6 and got[2] > 0
         # the recovered plane is the scene's plane

@@ -9,7 +9,7 @@ nc, npts, cap = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 s = make_scene(nc, npts)
 opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
-t = time.time(); plane, inl = opt.ransac_plane(s.pose_true, 4096, 0.01, 7, which=0); dt = time.time() - t
+t = time.time(); plane, inl, _ = opt.ransac_plane(s.pose_true, 4096, 0.01, 7, which=0); dt = time.time() - t
 print(f"ransac 4096 hyp x {nc*npts:.3g} pts: {dt:.2f} s, inliers {inl} of {nc*npts}, plane {plane}, truth {s.plane}", flush=True)
 rng = np.random.default_rng(1)
 starts = s.pose_true + rng.uniform(-1, 1, (64, 6)) * np.array([0.01] * 3 + [0.04] * 3)
