@@ -16,9 +16,13 @@ Scaling is weak: every rank scores 10^6 candidates of an N x 10^6 grid (axis 0
 is N times longer), so `value` = N * 10^6 * 6*10^6 residuals / step time.
 
 Printed on rank 0 as ONE JSON line; extra objects:
-  roofline      achieved algorithmic FLOP/s of the residual kernel (8 FLOP per
-                residual) from HIP events on the library's own stream, against
-                the 157.3 TFLOP/s FP32 matrix/vector peak.
+  roofline      the residual kernel against the pipe that executes it: matrix FLOP
+                per residual x residuals / HIP-event kernel time (events on the
+                library's own stream) over the dense peak of that pipe (bf16: 2.5
+                PFLOP/s; FP32-input MFMA: 157.3 TFLOP/s).  The 8-FLOP algorithmic
+                figure against the FP32 peak is the named sub-object algorithmic_fp32.
+  roofline_f32  the same for a few untimed steps of the FP32-input MFMA kernel.
+  roofline_gd   the exact path's part kernel during the descent (FP64 VALU issue).
   cpu_baseline  the CPU oracle (a port of the reference's serial loop) timed on
                 a bounded candidate sample of the same workload, rank 0, N = 1.
 """
@@ -35,28 +39,42 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X FP32 vector == FP32-input MFMA peak
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak
+PEAK_FP64_LANE_OPS = 256 * 4 * 16 * 2.4e9   # FP64-rate VALU lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
 FLOP_PER_RESIDUAL = 8             # 4 mul + 3 add (K=4 dot) + 1 add into the running sum
-EXECUTED_FLOP_PER_RESIDUAL = {    # what the matrix pipe actually executes per residual
-    "bf16x3": 2 * 32 + 1,         # one 16x16x32 bf16 MFMA per 256 residuals + the |.| add
-    "f32": 2 * 4 + 1,             # one 16x16x4 f32 MFMA per 256 residuals + the |.| add
-    "bf16x3wide": 2 * 32 + 1,     # two 32x32x16 bf16 MFMAs per 1024 residuals + the |.| add
+MATRIX_FLOP_PER_RESIDUAL = {      # what the matrix pipe executes per residual
+    "bf16x3": 2 * 32,             # one 16x16x32 bf16 MFMA (16384 FLOP) per 256 residuals
+    "f32": 2 * 4,                 # one 16x16x4 f32 MFMA (2048 FLOP) per 256 residuals
+    "bf16x3wide": 2 * 32,         # two 32x32x16 bf16 MFMAs per 1024 residuals
 }
+MATRIX_PEAK_TFLOPS = {"bf16x3": PEAK_BF16_TFLOPS, "f32": PEAK_FP32_TFLOPS, "bf16x3wide": PEAK_BF16_TFLOPS}
 KERNEL_NAME = {"bf16x3": "residual_bf16x3_kernel", "f32": "residual_mfma_kernel",
                "bf16x3wide": "residual_bf16x3_wide_kernel"}
+KERNEL_KIND = {"bf16x3": 0, "f32": 1, "bf16x3wide": 2}
+# VALU instructions the part kernel of the exact path executes per (pose, point), from the
+# SQ_INSTS_VALU counter of the committed PMC pass (profiles/): the unit of the GD leg's roofline
+EXACT_VALU_PER_POINT_FILE = os.path.join(ROOT, "profiles", "r2_pmc_split_chain_kernel.json")
+
+
+def quoted_counter(path, key):
+    try:
+        return json.load(open(path))["derived"][key]
+    except Exception:
+        return None
 
 
 def hbm_traffic_per_launch(args):
-    """HBM bytes per launch of the residual kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, plus WRITE_SIZE).
-    Counters are collected offline (tools/profile_r1.sh), so the figure is only quoted
-    for the workload it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_residual_kernel.json")
-    if not os.path.exists(path) or (args.clouds, args.points, args.axis, args.kernel) != (20, 300_000, 10, "bf16x3"):
-        return None
-    try:
-        return json.load(open(path))["derived"]["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        return None
+    """HBM bytes per launch of the residual kernel, QUOTED from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, plus WRITE_SIZE): counters are
+    collected in their own runs (tools/profile_r2.sh), never inside the benchmark, so the figure is
+    given only for the workload it was measured on, with its source; otherwise null."""
+    if (args.workload, args.clouds, args.points, args.axis, args.kernel) != ("c2", 20, 300_000, 10, "bf16x3"):
+        return None, None
+    for name in ("r2_pmc_residual_kernel.json", "r1_pmc_residual_kernel.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        v = quoted_counter(path, "hbm_traffic_bytes_per_launch")
+        if v is not None:
+            return v, "profiles/" + name
+    return None, None
 
 
 def parse():
@@ -73,7 +91,17 @@ def parse():
                     help="fast-path kernel: exact bf16x3 operand split on the bf16 matrix pipe, or FP32-input MFMA")
     ap.add_argument("--gd-iterations", type=int, default=-1,
                     help="iteration cap of the untimed GD refinement (-1 = reference's 10000, 0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2: 20 x 300k points, 10^6 candidates per GPU (weak scaling, the metric's configuration); "
+                         "c3: 100 x 1M points, ONE 10^7-candidate grid cut into N shards (strong scaling)")
+    ap.add_argument("--search", choices=["dense", "separable"], default="dense",
+                    help="how the timed step scores the grid (value and roofline are only reported for dense)")
+    ap.add_argument("--f32-steps", type=int, default=3,
+                    help="untimed steps of the FP32-input MFMA kernel for roofline_f32 (0 = skip)")
+    a = ap.parse_args()
+    if a.workload == "c3":
+        a.clouds, a.points = 100, 1_000_000
+    return a
 
 
 def main():
@@ -119,14 +147,25 @@ def main():
     opt.set_plane(scene.plane)
     opt.set_fast_kernel({"bf16x3": 0, "f32": 1, "bf16x3wide": 2}[args.kernel])
 
-    n = args.axis
-    counts = [n * world, n, n, n, n, n]
-    steps_mm = 40.0 / (n - 1)
-    steps_deg = 10.0 / (n - 1)
-    grid = cc.Grid.make([-20] * 3 + [-5] * 3, [steps_mm] * 3 + [steps_deg] * 3, counts)
-    total = grid.size
-    per_rank = total // world
-    begin, end = rank * per_rank, (rank + 1) * per_rank      # total = world * per_rank exactly
+    if args.workload == "c3":
+        # one grid for the whole job, (20,20,25 | 10,10,10) = 10^7 candidates, contiguous shards
+        counts = [20, 20, 25, 10, 10, 10]
+        grid = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (c - 1) for c in counts[:3]] + [10.0 / (c - 1) for c in counts[3:]],
+                            counts)
+        total = grid.size
+        begin, end = (total * rank) // world, (total * (rank + 1)) // world
+        scaling = "strong"
+    else:
+        n = args.axis
+        counts = [n * world, n, n, n, n, n]
+        steps_mm = 40.0 / (n - 1)
+        steps_deg = 10.0 / (n - 1)
+        grid = cc.Grid.make([-20] * 3 + [-5] * 3, [steps_mm] * 3 + [steps_deg] * 3, counts)
+        total = grid.size
+        begin, end = rank * (total // world), (rank + 1) * (total // world)      # total = world * per_rank exactly
+        scaling = "weak"
+    per_rank = end - begin
+    opt.set_search_mode(1 if args.search == "separable" else 0)
 
     from cameracalibration_amd.distributed import merge_argmin
 
@@ -157,10 +196,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    residuals_step = float(per_rank) * scene.n_points * world
+    residuals_step = float(total) * scene.n_points if args.workload == "c3" else float(per_rank) * scene.n_points * world
     value = residuals_step * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    ach_tflops = (residuals_rank * FLOP_PER_RESIDUAL) / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    res_per_s = residuals_rank / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0      # this rank's kernel rate
+    traffic, traffic_source = hbm_traffic_per_launch(args)
+
+    def roofline_of(kernel, rate, avg_ms):
+        mf, peak = MATRIX_FLOP_PER_RESIDUAL[kernel], MATRIX_PEAK_TFLOPS[kernel]
+        ach = rate * mf / 1e12
+        return {
+            "bound": "mfma",
+            "achieved": ach,
+            "peak": peak,
+            "unit": "TFLOP/s",
+            "frac": ach / peak,
+            "kernel": KERNEL_NAME[kernel],
+            "kernel_avg_ms": avg_ms,
+            "flop_per_residual": mf,
+            "residuals_per_s": rate,
+            "pipe": "FP32-input matrix instruction (16x16x4), same peak as the FP32 vector unit" if kernel == "f32"
+                    else "dense bf16 matrix pipe; both FP32 operands enter as exact three-way bf16 splits",
+            # the yardstick the task names: 8 algorithmic FLOP per residual against the FP32 peak.  Not a
+            # roofline fraction for the bf16 kernels (they do not run on that pipe), hence a field of its own.
+            "algorithmic_fp32": {"flop_per_residual": FLOP_PER_RESIDUAL, "achieved": rate * FLOP_PER_RESIDUAL / 1e12,
+                                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                 "ratio": rate * FLOP_PER_RESIDUAL / 1e12 / PEAK_FP32_TFLOPS},
+        }
 
     out = {
         "metric": "point-to-plane residuals/sec (whole node) + time-to-converged flange_T_camera",
@@ -171,47 +233,53 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         # operands are FP32; the default kernel feeds them to the bf16 matrix pipe as an exact
         # three-way bf16 split and accumulates in FP32 (same 1e-5 tolerance as the FP32 kernel)
         "dtype": "f32" if args.kernel == "f32" else "f32 (bf16x3 split operands, f32 accumulate)",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic {args.clouds} poses x {args.points} pts/cloud, "
-                        f"{per_rank}-candidate combinatorial grid per GPU (discrete search step)",
+            "workload": (f"synthetic {args.clouds} poses x {args.points} pts/cloud, one {total}-candidate grid in "
+                         f"{world} contiguous shards (discrete search step)") if args.workload == "c3" else
+                        (f"synthetic {args.clouds} poses x {args.points} pts/cloud, "
+                         f"{per_rank}-candidate combinatorial grid per GPU (discrete search step)"),
             "clouds": args.clouds,
             "points_per_cloud": args.points,
             "candidates_per_gpu": per_rank,
             "candidates_total": total,
+            "search": args.search,
             "parallelism": f"candidate shards x{world}, RCCL all-gather argmin" if world > 1 else "single GPU",
-        },
-        "roofline": {
-            "bound": "mfma",
-            "achieved": ach_tflops,
-            "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": ach_tflops / PEAK_FP32_TFLOPS,
-            "traffic": hbm_traffic_per_launch(args),
-            "kernel": KERNEL_NAME[args.kernel],
-            "kernel_avg_ms": kernel_ms / max(launches, 1),
-            "flop_per_residual": FLOP_PER_RESIDUAL,
-            "note": "algorithmic FP32 work (8 FLOP/residual) against the FP32 peak, the yardstick of the task; "
-                    "the bf16x3 kernel can exceed 1.0 because the products run on the bf16 pipe (see matrix_pipe)",
-            "matrix_pipe": {
-                "executed_flop_per_residual": EXECUTED_FLOP_PER_RESIDUAL[args.kernel],
-                "achieved": ach_tflops / FLOP_PER_RESIDUAL * EXECUTED_FLOP_PER_RESIDUAL[args.kernel],
-                "peak": PEAK_FP32_TFLOPS if args.kernel == "f32" else PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": ach_tflops / FLOP_PER_RESIDUAL * EXECUTED_FLOP_PER_RESIDUAL[args.kernel]
-                        / (PEAK_FP32_TFLOPS if args.kernel == "f32" else PEAK_BF16_TFLOPS),
-            },
         },
         "best_index": idx,
         "best_cost": cost,
+        "n_rescored": int(st.n_rescored),
+        "rescore_band": {"abs": st.band_abs, "rel": st.band_rel},
     }
+    if args.search == "dense":
+        out["roofline"] = roofline_of(args.kernel, res_per_s, kernel_ms / max(launches, 1))
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_source"] = traffic_source
+    else:
+        out["roofline"] = None       # the separable pass evaluates no residual one by one: nothing to price
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.workload == "c2":
+        # ---- untimed: the FP32-input MFMA kernel on the same workload (its own roofline line) ----
+        if args.f32_steps > 0 and args.kernel != "f32" and args.search == "dense":
+            opt.set_fast_kernel(KERNEL_KIND["f32"])
+            opt.grid_search(scene.pose_init, grid, begin, end)
+            ms = res = 0.0
+            n_l = 0
+            for _ in range(args.f32_steps):
+                i32, c32, _, st32 = opt.grid_search(scene.pose_init, grid, begin, end)
+                ms += st32.kernel_ms
+                res += st32.residuals
+                n_l += st32.kernel_launches
+            opt.set_fast_kernel(KERNEL_KIND[args.kernel])
+            out["roofline_f32"] = roofline_of("f32", res / (ms * 1e-3), ms / max(n_l, 1))
+            out["roofline_f32"]["steps"] = args.f32_steps
+            out["roofline_f32"]["same_result"] = bool(i32 == idx and c32 == cost)
+        opt.set_search_mode(0)
         # ---- untimed: the same search by the separable pass (one histogram pass per rotation
         # answers all its translations; no residual is evaluated one by one, so this is NOT
         # part of `value` or of the roofline) ----
@@ -243,6 +311,33 @@ def main():
             t2 = time.perf_counter()
             r = opt.gradient_descent(pose2, o)
             t3 = time.perf_counter()
+            # the same descent once more with device timers on: roofline of the exact path's part kernel
+            opt.set_profiling(True)
+            opt.profile(reset=True)
+            r_p = opt.gradient_descent(pose2, o)
+            pr = opt.profile()
+            opt.set_profiling(False)
+            vpp = quoted_counter(EXACT_VALU_PER_POINT_FILE, "valu_instructions_per_pose_point")
+            if pr.split_chain_ms > 0:
+                rate = pr.split_pose_points / (pr.split_chain_ms * 1e-3)
+                out["roofline_gd"] = {
+                    "bound": "fp64_valu_issue",
+                    "kernel": "split_chain_kernel",
+                    "kernel_avg_ms": pr.split_chain_ms / max(pr.split_requests, 1),
+                    "requests": int(pr.split_requests),
+                    "pose_points_per_s": rate,
+                    "us_per_pose": pr.split_chain_ms * 1e3 / (pr.split_pose_points / scene.n_points),
+                    "valu_instructions_per_pose_point": vpp,
+                    "valu_source": "profiles/" + os.path.basename(EXACT_VALU_PER_POINT_FILE) if vpp else None,
+                    "achieved": rate * vpp / 1e12 if vpp else None,
+                    "peak": PEAK_FP64_LANE_OPS / 1e12,
+                    "unit": "T lane-instructions/s (FP64-rate VALU: 16 lanes per SIMD and cycle)",
+                    "frac": rate * vpp / PEAK_FP64_LANE_OPS if vpp else None,
+                    "traffic": None,
+                    "other_kernels_ms": {"split_finish_kernel": pr.split_finish_ms, "exact_chain_kernel": pr.whole_chain_ms,
+                                         "screen_cost_kernel+reduce": pr.screen_ms},
+                    "same_iterates": bool(np.array_equal(r_p.xval, r.xval) and r_p.iterations == r.iterations),
+                }
             out["time_to_converged_s"] = t3 - t1
             out["time_to_converged_phases_s"] = {"dense_search": t2 - t1, "gradient_descent": t3 - t2,
                                                  "separable_search_instead": sep_ms * 1e-3}
@@ -255,7 +350,7 @@ def main():
         if args.cpu_candidates > 0:
             from oracle import oracle as O
             osc = O.OracleScene(scene.clouds, scene.base_T_flange)
-            og = O.make_grid([-20] * 3 + [-5] * 3, [steps_mm] * 3 + [steps_deg] * 3, counts)
+            og = O.make_grid([grid.min[k] for k in range(6)], [grid.step[k] for k in range(6)], counts)
             nc = args.cpu_candidates
             t1 = time.perf_counter()
             bi, bc, _, costs = osc.grid_search(scene.plane, scene.pose_init, og, 0, nc, want_costs=True)

@@ -78,6 +78,17 @@ class GridStats(C.Structure):
     ]
 
 
+class Profile(C.Structure):
+    """ccal_profile: device-time counters of the exact and screening passes."""
+
+    _fields_ = [
+        ("split_chain_ms", C.c_double), ("split_finish_ms", C.c_double), ("split_pose_points", C.c_double),
+        ("split_requests", C.c_int64),
+        ("whole_chain_ms", C.c_double), ("whole_pose_points", C.c_double), ("whole_requests", C.c_int64),
+        ("screen_ms", C.c_double), ("screen_pose_points", C.c_double), ("screen_requests", C.c_int64),
+    ]
+
+
 class GdOptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int),
@@ -146,6 +157,8 @@ SIGNATURES = {
     "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_gd_screening": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_chain_split": (C.c_int, [_CTX, C.c_int]),
+    "ccal_set_profiling": (C.c_int, [_CTX, C.c_int]),
+    "ccal_get_profile": (C.c_int, [_CTX, _P(Profile), C.c_int]),
     "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
     "ccal_write_config": (C.c_int, [C.c_char_p, C.c_char_p, _D]),
     "ccal_grid_default": (None, [_P(Grid)]),
@@ -303,6 +316,15 @@ class Optimizer:
         """A descent's small exact requests cut every (pose, cloud) sum into concurrently folded parts
         (default on; results are identical either way)."""
         self._check(self._lib.ccal_set_chain_split(self._ctx, 1 if on else 0))
+
+    def set_profiling(self, on: bool) -> None:
+        """HIP-event timing of the exact and screening kernels (read with ``profile()``)."""
+        self._check(self._lib.ccal_set_profiling(self._ctx, 1 if on else 0))
+
+    def profile(self, reset: bool = True) -> Profile:
+        p = Profile()
+        self._check(self._lib.ccal_get_profile(self._ctx, C.byref(p), 1 if reset else 0))
+        return p
 
     def set_plane(self, plane: Sequence[float]) -> None:
         p = np.ascontiguousarray(plane, dtype=np.float32)

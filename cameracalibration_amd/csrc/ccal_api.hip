@@ -293,6 +293,8 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     ctx->split_maps.release();
     ctx->split_first.release();
     ctx->static_out.release();
+    for (hipEvent_t& e : ctx->prof_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;
@@ -638,6 +640,8 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu &&
                            cs.seg_sums_valid &&
                            (int64_t)nb * cs.total_segs * (int64_t)sizeof(SegMap) <= ((int64_t)1 << 30);   // records: at most 1 GiB
+        const bool prof = ctx->profiling;
+        if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
         if (split) {
             // parts per chain: enough workgroups to fill the chip several times over (measured on 620
             // chains: 4 parts 0.578 s, 8 parts 0.562 s, 12 parts 0.560 s per descent)
@@ -649,6 +653,7 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
                                cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
                                cs.seg_sums.as<double>(), cs.total_segs, ctx->split_maps.as<SegMap>(),
                                ctx->split_first.as<double>());
+            if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
             hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)chains), dim3(64), 0, ctx->stream, cs.xs.as<float>(),
                                cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
                                cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
@@ -658,7 +663,25 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
             launch_exact_chains(ctx, cs, nb, per_cloud_max != nullptr, ExactTables{mats, planes, hsum, hmax});
         }
         CCAL_HIP(ctx, hipGetLastError());
+        if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (prof) {
+            float ms = 0.f, ms2 = 0.f;
+            const double pp = (double)nb * (double)cs.total_pts;
+            if (split) {
+                if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess &&
+                    hipEventElapsedTime(&ms2, ctx->prof_ev[1], ctx->prof_ev[2]) == hipSuccess) {
+                    ctx->prof.split_chain_ms += ms;
+                    ctx->prof.split_finish_ms += ms2;
+                    ctx->prof.split_pose_points += pp;
+                    ++ctx->prof.split_requests;
+                }
+            } else if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[2]) == hipSuccess) {
+                ctx->prof.whole_chain_ms += ms;
+                ctx->prof.whole_pose_points += pp;
+                ++ctx->prof.whole_requests;
+            }
+        }
         ctx->sets[which].seg_sums_valid = true;
         if (split) {
             for (size_t i = 0; i < n_out; ++i) ctx->split_resummed += (int64_t)hmax[i];
@@ -778,13 +801,23 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
         CCAL_HIP(ctx, ctx->screen_w.ensure((size_t)nb * C * 4 * sizeof(float)));
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->screen_w.p, w, (size_t)nb * C * 4 * sizeof(float), hipMemcpyHostToDevice,
                                      ctx->stream));
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
         hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
                            cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
                            ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
         hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 3) / 4), dim3(256), 0, ctx->stream,
                            ctx->screen_partial.as<double>(), cs.cloud_block_off_dev.as<int>(), nb, C, sums);
         CCAL_HIP(ctx, hipGetLastError());
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->profiling) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[2]) == hipSuccess) {
+                ctx->prof.screen_ms += ms;
+                ctx->prof.screen_pose_points += (double)nb * (double)cs.total_pts;
+                ++ctx->prof.screen_requests;
+            }
+        }
         for (int k = 0; k < nb; ++k) {
             double f = 0.0, b = 0.0;
             for (int j = 0; j < C; ++j) {
@@ -803,6 +836,26 @@ extern "C" int ccal_eval_bounded(ccal_ctx* ctx, int which, int n_poses, const do
                                  const double* planes4, double* cost, double* bound)
 {
     return ccal::eval_screen(ctx, which, n_poses, poses6, planes4, cost, bound);
+}
+
+extern "C" int ccal_set_profiling(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (on) {
+        if (int rc = bind(ctx)) return rc;
+        for (hipEvent_t& e : ctx->prof_ev)
+            if (!e) CCAL_HIP(ctx, hipEventCreate(&e));
+    }
+    ctx->profiling = on != 0;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_get_profile(ccal_ctx* ctx, ccal_profile* out, int reset)
+{
+    if (!ctx || !out) return CCAL_ERR_ARG;
+    *out = ctx->prof;
+    if (reset) ctx->prof = ccal_profile{};
+    return CCAL_OK;
 }
 
 extern "C" int ccal_set_chain_split(ccal_ctx* ctx, int on)

@@ -124,6 +124,9 @@ struct ccal_ctx {
     ccal::HostBuf screen_in, screen_out; // four-vectors and per-(pose, cloud) sums of the screening pass
     ccal::DevBuf screen_partial, screen_w;
     bool gd_screening = true;            // line-search trials are first screened on the fast path
+    bool profiling = false;              // HIP events around the exact and screening kernels
+    hipEvent_t prof_ev[3] = {nullptr, nullptr, nullptr};
+    ccal_profile prof = {};
     double* static_scratch = nullptr;    // this device's address of the library's static scratch array
     ccal::HostBuf static_out;            // pinned result slot of ccal_fit_plane_lsq_static (made at create)
     ccal::DevBuf mats_buf, planes_buf, psum_buf, osum_buf, omax_buf, tbl_buf, dist_buf;

@@ -296,6 +296,26 @@ int  ccal_set_gd_screening(ccal_ctx* ctx, int on);
  * guess did not fit.  Same values on or off (the ordered sum of :305 either way). */
 int  ccal_set_chain_split(ccal_ctx* ctx, int on);
 
+/* Device-time counters of the exact and screening passes (off by default; HIP events on the
+ * context's stream around the kernels).  The reference times host code with its TIC/TOC macros
+ * (src/helpers.hpp:222-234); this is their device-side counterpart and feeds the roofline
+ * figures of the benchmark.  pose_points = sum over requests of poses x points of the set. */
+typedef struct {
+    double  split_chain_ms;      /* split_chain_kernel: chains cut into concurrently folded parts */
+    double  split_finish_ms;     /* split_finish_kernel: one wave per chain applies the parts     */
+    double  split_pose_points;
+    int64_t split_requests;
+    double  whole_chain_ms;      /* exact_chain_kernel: one workgroup per (pose, cloud) chain     */
+    double  whole_pose_points;
+    int64_t whole_requests;
+    double  screen_ms;           /* screen_cost_kernel + its reduction (FP32 line-search scores)  */
+    double  screen_pose_points;
+    int64_t screen_requests;
+} ccal_profile;
+int ccal_set_profiling(ccal_ctx* ctx, int on);
+/* Copies the counters; reset != 0 zeroes them afterwards. */
+int ccal_get_profile(ccal_ctx* ctx, ccal_profile* out, int reset);
+
 /* ---- host-side ingest and the whole run -------------------------------------
  * These three do not touch the GPU. */
 

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of this round: one kernel-trace/stats run of the benchmark and
+# PMC passes (each counter group in a run of its own, never together with a trace option) for the
+# residual kernel, the separable histogram kernel, the exact path's part kernel and the moment
+# kernel.  Run through gpurun from the repo root; summaries are written by tools/summarize_pmc.py.
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_r2
+mkdir -p $OUT
+BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-candidates 0"
+SHORT="python3 bench.py --steps 1 --warmup 1 --cpu-candidates 0 --gd-iterations 40 --f32-steps 1"
+echo "[profile] kernel trace"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
+pass() {   # tag, program..., then "--", counters...
+  local tag=$1; shift
+  local prog=()
+  while [ "$1" != "--" ]; do prog+=("$1"); shift; done
+  shift
+  echo "[profile] pmc $tag: $*"
+  timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$tag -o pmc -- "${prog[@]}" > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || { echo "pmc $tag failed"; tail -3 $OUT/pmc_$tag.err; return 1; }
+}
+pass fetch $SHORT -- FETCH_SIZE || exit 1
+pass write $SHORT -- WRITE_SIZE || exit 1
+pass issue $SHORT -- SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU || exit 1
+pass clock $SHORT -- GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MISS_sum || exit 1
+python3 tools/summarize_pmc.py $OUT > $OUT/summary.json && echo "[profile] summary written"
