@@ -19,6 +19,7 @@ from .binding import (  # noqa: F401
     Grid,
     GridStats,
     Optimizer,
+    comm_unique_id,
     device_count,
     filter_z,
     parse_pose,

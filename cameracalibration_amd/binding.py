@@ -171,6 +171,10 @@ SIGNATURES = {
     "ccal_grid_costs": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _F]),
     "ccal_grid_error_bound": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), _D, _D]),
     "ccal_argmin_merge": (C.c_int, [C.c_int, _D, _P(C.c_int64)]),
+    "ccal_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ccal_comm_create": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_char_p, _P(C.c_void_p)]),
+    "ccal_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ccal_argmin_allgather": (C.c_int, [_CTX, C.c_void_p, C.c_double, C.c_int64, _D, _P(C.c_int64), _P(C.c_int)]),
     "ccal_fit_plane_lsq": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_fit_plane_lsq_static": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_ransac_plane": (
@@ -249,6 +253,7 @@ class Optimizer:
 
     # -- lifetime ----------------------------------------------------------
     def close(self) -> None:
+        self.comm_destroy()
         if self._ctx:
             self._lib.ccal_destroy(self._ctx)
             self._ctx = _CTX()
@@ -445,6 +450,27 @@ class Optimizer:
         self._check(self._lib.ccal_grid_error_bound(self._ctx, which, _dptr(b), C.byref(g), C.byref(a), C.byref(r)))
         return float(a.value), float(r.value)
 
+    # -- the arg-min exchange over RCCL (one process per GPU) -----------------------
+    def comm_create(self, world_size: int, rank: int, unique_id: bytes) -> None:
+        """Collective: joins the RCCL communicator named by `unique_id` (comm_unique_id() of rank 0)."""
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        comm = C.c_void_p()
+        self._check(self._lib.ccal_comm_create(self._ctx, int(world_size), int(rank), unique_id, C.byref(comm)))
+        self._comm = comm
+
+    def comm_destroy(self) -> None:
+        if getattr(self, "_comm", None):
+            self._lib.ccal_comm_destroy(self._comm)
+            self._comm = None
+
+    def argmin_allgather(self, cost: float, index: int):
+        """(best_cost, best_index, winner_rank) over all ranks' (cost, index); index < 0 = empty shard."""
+        bc, bi, w = C.c_double(0.0), C.c_int64(-1), C.c_int(-1)
+        self._check(self._lib.ccal_argmin_allgather(self._ctx, self._comm, float(cost), int(index),
+                                                    C.byref(bc), C.byref(bi), C.byref(w)))
+        return float(bc.value), int(bi.value), int(w.value)
+
     def fit_plane(self, pose, which: int = CCAL_RAW) -> np.ndarray:
         p = np.ascontiguousarray(pose, dtype=np.float64)
         out = np.empty(4, dtype=np.float32)
@@ -490,6 +516,15 @@ class Optimizer:
             for r in res
         ]
         return out[0] if single else out
+
+
+def comm_unique_id() -> bytes:
+    """128 bytes naming a new RCCL communicator (rank 0 makes it, every rank passes it to comm_create)."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().ccal_comm_unique_id(buf)
+    if rc != 0:
+        raise CcalError(rc, "ccal_comm_unique_id (is librccl available?)")
+    return buf.raw
 
 
 def argmin_merge(costs: Sequence[float], indices: Sequence[int]) -> int:

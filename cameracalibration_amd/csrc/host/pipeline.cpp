@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <fstream>
@@ -28,12 +31,19 @@ using namespace ccal_host;
 
 namespace {
 
+// A failure with the status the C ABI reports for it.
+struct Failure : std::runtime_error {
+    int status;
+    Failure(int s, const std::string& what) : std::runtime_error(what), status(s) {}
+};
+
 struct Inputs {
     std::vector<Cloud> raw, down;
     std::vector<double> base_T_flange;   // per cloud, already mapped (:290)
     double pose_init[6];
     ccal_grid grid;
     int n_gpus = 1;
+    bool share_gpus = false;  // <device><share>: more contexts than GPUs, round-robin (rehearsals, tests)
     int search_mode = CCAL_SEARCH_SEPARABLE;   // same result as the dense sweep, O(rotations x points) work
     ccal_gd_opts gd;
     std::string config_out;   // optional <output><config>: refined config written here
@@ -136,11 +146,12 @@ Inputs load_inputs(const std::string& config_file, bool chatty)
         in.grid.count[k] = (int)num(*root, grp + ".count", in.grid.count[k]);
     }
     in.n_gpus = (int)num(*root, "data.device.gpus", 1);
+    in.share_gpus = num(*root, "data.device.share", 0) != 0;
     {
         const std::string mode = trim(root->get("data.search.mode", ""));
         if (mode == "dense") in.search_mode = CCAL_SEARCH_DENSE;
         else if (mode == "separable" || mode.empty()) in.search_mode = CCAL_SEARCH_SEPARABLE;
-        else throw std::runtime_error("config: <search><mode> must be dense or separable");
+        else throw Failure(CCAL_ERR_ARG, "config: <search><mode> must be dense or separable");
     }
     ccal_gd_default_opts(&in.gd);
     in.gd.max_iterations = (int)num(*root, "data.search.gd_max_iterations", in.gd.max_iterations);
@@ -153,9 +164,65 @@ struct Check {
     void operator()(int rc, const char* what) const
     {
         if (rc != CCAL_OK)
-            throw std::runtime_error(std::string(what) + ": " + (ctx ? ccal_last_error(ctx) : ccal_status_string(rc)));
+            throw Failure(rc, std::string(what) + ": " + (ctx ? ccal_last_error(ctx) : ccal_status_string(rc)));
     }
 };
+
+// One process per GPU: the run's place among its peers, from the environment of the launcher.
+//   CCAL_WORLD_SIZE, CCAL_RANK   number of processes and this one's index (default 1, 0)
+//   CCAL_LOCAL_RANK              GPU of this process (default: the rank)
+//   CCAL_COMM_FILE               rendezvous file: rank 0 writes the 128-byte communicator id there
+//                                (and removes it once every rank has joined), the others wait for it.
+//                                When set, the exchange runs even with one process.
+struct Peers {
+    int world = 1, rank = 0, local_rank = 0;
+    std::string comm_file;
+    bool exchange() const { return world > 1 || !comm_file.empty(); }
+};
+
+Peers peers_from_env()
+{
+    Peers p;
+    auto geti = [](const char* name, int dflt) {
+        const char* v = std::getenv(name);
+        return v && *v ? std::atoi(v) : dflt;
+    };
+    p.world = geti("CCAL_WORLD_SIZE", 1);
+    p.rank = geti("CCAL_RANK", 0);
+    p.local_rank = geti("CCAL_LOCAL_RANK", p.rank);
+    if (const char* f = std::getenv("CCAL_COMM_FILE")) p.comm_file = f;
+    if (p.world < 1 || p.rank < 0 || p.rank >= p.world) throw Failure(CCAL_ERR_ARG, "CCAL_RANK / CCAL_WORLD_SIZE out of range");
+    if (p.world > 1 && p.comm_file.empty()) throw Failure(CCAL_ERR_ARG, "CCAL_WORLD_SIZE > 1 needs CCAL_COMM_FILE");
+    return p;
+}
+
+ccal_comm* join_peers(ccal_ctx* ctx, const Peers& p)
+{
+    char id[CCAL_COMM_ID_BYTES];
+    const std::string tmp = p.comm_file + ".tmp";
+    if (p.rank == 0) {
+        if (ccal_comm_unique_id(id) != CCAL_OK) throw Failure(CCAL_ERR_DEVICE, "ccal_comm_unique_id failed (librccl missing?)");
+        {
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(id, sizeof id);
+            if (!f) throw Failure(CCAL_ERR_IO, "cannot write " + tmp);
+        }
+        if (std::rename(tmp.c_str(), p.comm_file.c_str()) != 0) throw Failure(CCAL_ERR_IO, "cannot create " + p.comm_file);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            std::ifstream f(p.comm_file, std::ios::binary);
+            if (f && f.read(id, sizeof id) && f.gcount() == (std::streamsize)sizeof id) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                throw Failure(CCAL_ERR_IO, "no communicator id in " + p.comm_file + " after 120 s");
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    ccal_comm* comm = nullptr;
+    Check{ctx}(ccal_comm_create(ctx, p.world, p.rank, id, &comm), "comm_create");
+    if (p.rank == 0) std::remove(p.comm_file.c_str());   // every rank has read it: comm_create is collective
+    return comm;
+}
 
 void upload(ccal_ctx* ctx, int which, const std::vector<Cloud>& clouds, const std::vector<double>& B)
 {
@@ -187,40 +254,56 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
                                const char* errors_path, int verbose, char* errbuf, size_t errbuf_len)
 {
     std::vector<ccal_ctx*> ctxs;
-    auto cleanup = [&]() { for (auto* c : ctxs) ccal_destroy(c); ctxs.clear(); };
+    ccal_comm* comm = nullptr;
+    auto cleanup = [&]() {
+        if (comm) ccal_comm_destroy(comm);
+        comm = nullptr;
+        for (auto* c : ctxs) ccal_destroy(c);
+        ctxs.clear();
+    };
     try {
-        if (!config_path) throw std::runtime_error("null config path");
-        const bool chatty = verbose != 0;
-        std::ofstream outfile(results_path ? results_path : "results.txt", std::ios_base::app);            // :567
-        std::ofstream errorfile(errors_path ? errors_path : "new_experiments_errors.txt", std::ios_base::app);  // :569
-        if (!outfile || !errorfile) throw std::runtime_error("cannot open the result files for appending");
-        outfile << "Results: " << config_path << std::endl;                                                 // :571
-        errorfile << "Results: " << config_path << std::endl;                                               // :572
+        if (!config_path) throw Failure(CCAL_ERR_ARG, "null config path");
+        const Peers peers = peers_from_env();
+        const bool writer = peers.rank == 0;              // one process writes the two text files
+        const bool chatty = verbose != 0 && writer;
+        std::ofstream outfile, errorfile;                 // left closed on the other ranks: writes go nowhere
+        if (writer) {
+            outfile.open(results_path ? results_path : "results.txt", std::ios_base::app);                     // :567
+            errorfile.open(errors_path ? errors_path : "new_experiments_errors.txt", std::ios_base::app);     // :569
+            if (!outfile || !errorfile) throw Failure(CCAL_ERR_IO, "cannot open the result files for appending");
+            outfile << "Results: " << config_path << std::endl;                                                // :571
+            errorfile << "Results: " << config_path << std::endl;                                              // :572
+        }
 
         Inputs in = load_inputs(config_path, chatty);
         const int C = (int)in.raw.size();
         const int avail = ccal_device_count();
-        if (avail < 1) throw std::runtime_error("no GPU visible: the optimiser has no CPU path");
-        const int n_gpus = std::max(1, std::min(in.n_gpus, avail));
-        for (int d = 0; d < n_gpus; ++d) {
+        if (avail < 1) throw Failure(CCAL_ERR_DEVICE, "no GPU visible: the optimiser has no CPU path");
+        // contexts of this process: one per GPU (one host thread each); with <device><share> the
+        // configured number even on fewer GPUs, round-robin.  One process per GPU: exactly one.
+        int n_ctx = std::max(1, in.share_gpus ? in.n_gpus : std::min(in.n_gpus, avail));
+        if (peers.world > 1) n_ctx = 1;
+        for (int d = 0; d < n_ctx; ++d) {
             ccal_ctx* c = nullptr;
-            Check{nullptr}(ccal_create(d, &c), "ccal_create");
+            const int dev = peers.world > 1 ? peers.local_rank % avail : d % avail;
+            Check{nullptr}(ccal_create(dev, &c), "ccal_create");
             ctxs.push_back(c);
         }
         ccal_ctx* ctx = ctxs[0];
+        if (peers.exchange()) comm = join_peers(ctx, peers);
         // raw clouds go to the device once; VoxelGrid(0.02) (:196-205) runs there
         upload(ctx, CCAL_RAW, in.raw, in.base_T_flange);
         std::vector<size_t> n_down(C);
         Check{ctx}(ccal_downsample_raw(ctx, 0.02f, n_down.data()), "downsample_raw");
         if (chatty)
             for (int j = 0; j < C; ++j) std::cout << "Filtered Clouds Size: " << n_down[j] << std::endl;   // :204
-        if (n_gpus > 1) {
+        if (n_ctx > 1) {
             in.down.resize(C);
             for (int j = 0; j < C; ++j) {
                 in.down[j].resize(3 * n_down[j]);
                 Check{ctx}(ccal_download_cloud(ctx, CCAL_DOWNSAMPLED, j, in.down[j].data()), "download_cloud");
             }
-            for (int d = 1; d < n_gpus; ++d) upload(ctxs[d], CCAL_DOWNSAMPLED, in.down, in.base_T_flange);
+            for (int d = 1; d < n_ctx; ++d) upload(ctxs[d], CCAL_DOWNSAMPLED, in.down, in.base_T_flange);
         }
 
         // plane from every raw point carried to the base frame by the initial pose (:240-277)
@@ -239,25 +322,39 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         Check{ctx}(ccal_eval(ctx, CCAL_DOWNSAMPLED, 1, in.pose_init, nullptr, &true_err, nullptr, nullptr), "eval");
         if (chatty) std::cout << "True: " << true_err;                                                      // :529
         const int64_t total = ccal_grid_size(&in.grid);
-        if (total <= 0) throw std::runtime_error("config: empty search grid");
-        std::vector<double> costs(n_gpus, 1e9), poses(6 * (size_t)n_gpus);
-        std::vector<int64_t> idxs(n_gpus, -1);
-        std::vector<int> rcs(n_gpus, CCAL_OK);
+        if (total <= 0) throw Failure(CCAL_ERR_ARG, "config: empty search grid");
+        // this process's contiguous share of the grid, cut again over its contexts
+        const int64_t p_begin = total * peers.rank / peers.world, p_end = total * (peers.rank + 1) / peers.world;
+        std::vector<double> costs(n_ctx, 1e9), poses(6 * (size_t)n_ctx);
+        std::vector<int64_t> idxs(n_ctx, -1);
+        std::vector<int> rcs(n_ctx, CCAL_OK);
         std::vector<std::thread> th;
-        for (int d = 0; d < n_gpus; ++d) {
-            const int64_t b = total * d / n_gpus, e = total * (d + 1) / n_gpus;
+        for (int d = 0; d < n_ctx; ++d) {
+            const int64_t b = p_begin + (p_end - p_begin) * d / n_ctx, e = p_begin + (p_end - p_begin) * (d + 1) / n_ctx;
             th.emplace_back([&, d, b, e]() {
                 rcs[d] = ccal_grid_search(ctxs[d], CCAL_DOWNSAMPLED, in.pose_init, &in.grid, b, e, &idxs[d],
                                           &costs[d], &poses[6 * (size_t)d], nullptr);
             });
         }
         for (auto& t : th) t.join();
-        for (int d = 0; d < n_gpus; ++d) Check{ctxs[d]}(rcs[d], "grid_search");
-        const int w = ccal_argmin_merge(n_gpus, costs.data(), idxs.data());
+        for (int d = 0; d < n_ctx; ++d) Check{ctxs[d]}(rcs[d], "grid_search");
+        const int w = ccal_argmin_merge(n_ctx, costs.data(), idxs.data());
+        double best_cost = w >= 0 ? costs[w] : 1e9;
+        int64_t best_index = w >= 0 ? idxs[w] : -1;
+        if (comm) {
+            // the one exchange between processes: (cost, index) records over RCCL, lexicographic minimum
+            Check{ctx}(ccal_argmin_allgather(ctx, comm, best_cost, best_index, &best_cost, &best_index, nullptr),
+                       "argmin_allgather");
+        }
         double best[6];
-        std::memcpy(best, w >= 0 ? &poses[6 * (size_t)w] : in.pose_init, sizeof best);
+        std::memcpy(best, in.pose_init, sizeof best);
+        if (best_index >= 0) ccal_grid_pose(&in.grid, in.pose_init, best_index, best);
+        if (!writer) {            // gradient descent runs on one GPU: the other processes are done
+            cleanup();
+            return CCAL_OK;
+        }
         if (chatty) {
-            std::cout << "Error: " << (w >= 0 ? costs[w] : 1e9) << std::endl << "Best Transformation:" << std::endl;
+            std::cout << "Error: " << best_cost << std::endl << "Best Transformation:" << std::endl;
             for (double v : best) std::cout << v << " ";
             std::cout << std::endl;
         }
@@ -282,7 +379,7 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         outfile << plane[3] << std::endl;
         print_error(ctx, r6.xval, C, errorfile);                                                            // :464
         if (!in.config_out.empty() && ccal_write_config(config_path, in.config_out.c_str(), r6.xval) != CCAL_OK)
-            throw std::runtime_error("cannot write " + in.config_out);
+            throw Failure(CCAL_ERR_IO, "cannot write " + in.config_out);
 
         // ---- gradientDescentWithPlane (:466-524) --------------------------------------
         double x10[10];
@@ -310,6 +407,9 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
             std::strncpy(errbuf, e.what(), errbuf_len - 1);
             errbuf[errbuf_len - 1] = 0;
         }
+        // device trouble, bad arguments and capacity keep their status; everything that went wrong
+        // while reading or writing files (the reference's bare `throw;`s) is an I/O error
+        if (const Failure* f = dynamic_cast<const Failure*>(&e)) return f->status;
         return CCAL_ERR_IO;
     }
 }

@@ -205,6 +205,23 @@ int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose[6],
 int ccal_grid_costs(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
                     int64_t begin, int64_t end, float* cost_out);
 
+/* The arg-min exchange of a one-process-per-GPU run over RCCL (the one collective of the path;
+ * the reference is a single process and has none).  Every rank searches its own candidate
+ * range with ccal_grid_search and then calls ccal_argmin_allgather with its (cost, index)
+ * (index < 0: empty shard): one ncclAllGather of 16-byte records on the context's stream, and
+ * every rank takes the lexicographic minimum -- lowest index among equal costs, as the single
+ * scan of :542 keeps it.  Rendezvous: rank 0 calls ccal_comm_unique_id and hands the 128 bytes
+ * to the other ranks by whatever channel the launcher has (a file, MPI, a socket); every rank
+ * then calls ccal_comm_create (collective).  librccl is loaded at the first of these calls. */
+#define CCAL_COMM_ID_BYTES 128
+typedef struct ccal_comm ccal_comm;
+int ccal_comm_unique_id(char id_out[CCAL_COMM_ID_BYTES]);
+int ccal_comm_create(ccal_ctx* ctx, int world_size, int rank, const char id[CCAL_COMM_ID_BYTES],
+                     ccal_comm** out);
+int ccal_comm_destroy(ccal_comm* comm);
+int ccal_argmin_allgather(ccal_ctx* ctx, ccal_comm* comm, double cost, int64_t index,
+                          double* best_cost, int64_t* best_index, int* winner_rank);
+
 /* The bound ccal_grid_search works with, for the current search mode and fast kernel: for
  * every candidate c of the grid, |ccal_grid_costs value of c - ccal_eval cost of c| <=
  * *abs_out + *rel_out * (ccal_grid_costs value of c).  Derived on the host from the cloud
@@ -352,7 +369,18 @@ int  ccal_write_config(const char* config_in, const char* config_out, const doub
  * three drivers (camera_calibration_optimization.cpp:560-581, :148-278,
  * :526-558, :411-524).  Reads the reference's XML config, appends to the two
  * text files in the reference's format.  On failure returns a negative status
- * and copies a message into errbuf. */
+ * and copies a message into errbuf: CCAL_ERR_IO for anything that went wrong
+ * reading or writing files (the reference's bare `throw;`, helpers.cpp:126,205),
+ * CCAL_ERR_DEVICE for a missing GPU or a HIP / RCCL failure, CCAL_ERR_ARG for
+ * a config that asks for something impossible.
+ * Optional config nodes beside the reference's schema: <search> (grid extent,
+ * mode, iteration cap), <device><gpus>N</gpus> (contexts of this process, one
+ * host thread each; capped at the GPUs present unless <share>1</share> allows
+ * several contexts per GPU), <output><config>.
+ * One process per GPU: with CCAL_WORLD_SIZE / CCAL_RANK / CCAL_LOCAL_RANK /
+ * CCAL_COMM_FILE in the environment every process loads the inputs, searches its
+ * contiguous share of the grid and joins one ccal_argmin_allgather; rank 0 then
+ * refines and writes the files, the others return after the exchange. */
 int  ccal_run_config(const char* config_path, const char* results_path, const char* errors_path,
                      int verbose, char* errbuf, size_t errbuf_len);
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from cameracalibration_amd.synthetic import make_scene
-from tests.test_loader_cpu import write_pcd_binary, write_ply_binary
+from tests.test_loader_cpu import write_pcd_ascii, write_pcd_binary, write_ply_ascii, write_ply_binary
 
 pytestmark = pytest.mark.gpu
 
@@ -27,29 +27,64 @@ def zyx_pose(T):
                      np.arctan2(R[2, 1], R[2, 2])])
 
 
-def build_case(tmp, ccal):
-    s = make_scene(3, 20000, seed=77, ragged=True)
+def expected_raw(pts, fmt, metric):
+    """What readPointCloud (helpers.cpp:108-207) makes of the file written from `pts` -- stated in numpy,
+    independently of the product's readers: binary and %.9g text keep the float32 exactly; the .xyz text
+    is written with six decimals; a metric other than m divides in double and rounds to float."""
+    scale = {"m": 1.0, "cm": 100.0, "mm": 1000.0}[metric]
+    stored = (pts.astype(np.float64) * scale).astype(np.float32)
+    if fmt == "xyz":
+        stored = np.array([[np.float32(float("%.6f" % v)) for v in p] for p in stored], dtype=np.float32)
+    if metric == "m":
+        return stored, stored
+    return stored, (stored.astype(np.float64) / scale).astype(np.float32)
+
+
+def write_xyz(path, stored):
+    with open(path, "w") as f:
+        f.write("index x,y,z\n")
+        for i, p in enumerate(stored):
+            f.write("%d %.6f,%.6f,%.6f\n" % (i, p[0], p[1], p[2]))
+
+
+def build_case(tmp, text_formats=False, search_xml=None, device_xml="", n_points=20000):
+    """Writes clouds, IK file and config; returns everything the oracle side needs.  text_formats: ascii
+    PLY, ascii PCD and .xyz clouds in millimetres, the initial pose in millimetres and (non-integer)
+    degrees -- the branches of helpers.cpp:159-201 and of getTransVector / degreeToRadian(int)."""
+    s = make_scene(3, n_points, seed=77, ragged=True)
     os.makedirs(tmp / "pc")
     # document order 2,3,1 exercises mapping[k] = id - 1 (:161-163)
     order = [2, 3, 1]
-    files = []
+    metric = "mm" if text_formats else "m"
+    files, raw = [], []
     for k, cid in enumerate(order):
         pts = s.clouds[k].copy()
         pts[::997, 2] = 0.9                       # dropped by the z <= 0.8 filter
         pts[5::1009, 2] = np.float32(0.8)         # 0.800000011920929 > 0.8 in double: dropped too (:168)
-        if cid == 3:
-            path = str(tmp / "pc" / ("cloud_%d.pcd" % cid))
-            write_pcd_binary(path, pts)
+        fmt = {2: "ply", 3: "pcd", 1: "xyz" if text_formats else "ply"}[cid]
+        stored, read = expected_raw(pts, fmt, metric)
+        path = str(tmp / "pc" / ("cloud_%d.%s" % (cid, fmt)))
+        if fmt == "xyz":
+            write_xyz(path, stored)
+        elif fmt == "pcd":
+            (write_pcd_ascii if text_formats else write_pcd_binary)(path, stored)
         else:
-            path = str(tmp / "pc" / ("cloud_%d.ply" % cid))
-            write_ply_binary(path, pts)
+            (write_ply_ascii if text_formats else write_ply_binary)(path, stored)
         files.append(path)
+        raw.append(read[read[:, 2].astype(np.float64) <= 0.8])     # float z promoted to double (:168)
     rows = [None] * 3
     for k, cid in enumerate(order):
         rows[cid - 1] = zyx_pose(s.base_T_flange[k]) * np.array([1000, 1000, 1000, 1, 1, 1])   # mm in the file
     ik = tmp / "BaseToFlange.csv"
     ik.write_text("".join(",".join("%.6f" % v for v in r) + "\n" for r in rows))
-    init = s.pose_init
+    if text_formats:
+        init = s.pose_init * np.array([1000, 1000, 1000, 180 / np.pi, 180 / np.pi, 180 / np.pi])
+        value, t_metric, angle, scale = ", ".join("%.4f" % v for v in init), "mm", "degree", 1000.0
+    else:
+        value, t_metric, angle, scale = ",".join("%.6g" % v for v in s.pose_init), "m", "rad", 1.0
+    if search_xml is None:
+        search_xml = ("<translation_mm><min>-8</min><step>4</step><count>5</count></translation_mm>"
+                      "<rotation_deg><min>-4</min><step>2</step><count>5</count></rotation_deg>")
     cfg = tmp / "config.xml"
     cfg.write_text(f"""<?xml version="1.0"?>
 <data>
@@ -60,12 +95,12 @@ def build_case(tmp, ccal):
                 <location>{ik}</location>
             </inverse_kinematics>
             <approximate_transformation>
-                <angle>rad</angle>
-                <metric>m</metric>
-                <value>{",".join("%.6g" % v for v in init)}</value>
+                <angle>{angle}</angle>
+                <metric>{t_metric}</metric>
+                <value>{value}</value>
             </approximate_transformation>
         </transformations>
-        <metric>m</metric>
+        <metric>{metric}</metric>
         <clouds>
             <pointcloud>{files[0]}</pointcloud>
             <pointcloud>{files[1]}</pointcloud>
@@ -74,29 +109,26 @@ def build_case(tmp, ccal):
     </camera>
     <!-- extension nodes; without them the run uses the reference's 11^6 grid -->
     <search>
-        <translation_mm><min>-8</min><step>4</step><count>5</count></translation_mm>
-        <rotation_deg><min>-4</min><step>2</step><count>5</count></rotation_deg>
+        {search_xml}
         <gd_max_iterations>12</gd_max_iterations>
     </search>
+    {device_xml}
     <output><config>{tmp}/refined.xml</config></output>
 </data>
 """)
-    return cfg, files, order, ik, init
+    return {"cfg": cfg, "raw": raw, "order": order, "ik": ik, "value": value, "scale": scale,
+            "degree": angle == "degree"}
 
 
-def oracle_expected(O, ccal, cfg, files, order, ik, init):
-    raw = []
-    for f in files:
-        a = ccal.read_point_cloud(f)
-        raw.append(a[a[:, 2].astype(np.float64) <= 0.8])     # float z promoted to double (:168)
+def oracle_expected(O, case, grid=([-8] * 3 + [-4] * 3, [4] * 3 + [2] * 3, [5] * 6)):
+    cfg, raw, order = case["cfg"], case["raw"], case["order"]
     ds = [O.voxel_grid(c, 0.02) for c in raw]
-    ik_rows = [O.parse_pose_csv(l, scale=1000.0) for l in open(ik).read().split("\n") if l.strip()]
+    ik_rows = [O.parse_pose_csv(l, scale=1000.0) for l in open(case["ik"]).read().split("\n") if l.strip()]
     B = np.stack([O.pose_to_matrix(ik_rows[cid - 1]) for cid in order])
-    pose0 = O.parse_pose_csv(",".join("%.6g" % v for v in init))
+    pose0 = O.parse_pose_csv(case["value"], scale=case["scale"], degree=case["degree"])
     sraw, sds = O.OracleScene(raw, B), O.OracleScene(ds, B)
     plane = O.fit_plane(sraw.combined_cloud(pose0))
-    grid = O.make_grid([-8] * 3 + [-4] * 3, [4] * 3 + [2] * 3, [5] * 6)
-    _, _, best, _ = sds.grid_search(plane, pose0, grid)
+    _, _, best, _ = sds.grid_search(plane, pose0, O.make_grid(*grid))
     o = O.gd_default_opts()
     o.max_iterations = 12
     r6 = sds.gd_minimize(plane, best, o)
@@ -122,15 +154,25 @@ def oracle_expected(O, ccal, cfg, files, order, ik, init):
     return res, err, plane
 
 
-def test_cli_end_to_end(tmp_path, ccal, oracle, gpu_opt):
-    cfg, files, order, ik, init = build_case(tmp_path, ccal)
-    res, err, plane = oracle_expected(oracle, ccal, cfg, files, order, ik, init)
+def run_cli(tmp_path, cfg, env=None, timeout=280):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([CLI, str(cfg)], cwd=tmp_path, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def outputs(tmp_path):
+    return (open(tmp_path / "results.txt").read().split("\n"),
+            open(tmp_path / "new_experiments_errors.txt").read().split("\n"))
+
+
+def test_cli_end_to_end(tmp_path, oracle):
+    case = build_case(tmp_path)
+    res, err, plane = oracle_expected(oracle, case)
     assert os.path.exists(CLI), "build the CLI with make -C cameracalibration_amd/csrc"
     for run in (1, 2):                           # second run appends (:567-569)
-        p = subprocess.run([CLI, str(cfg)], cwd=tmp_path, capture_output=True, text=True, timeout=280)
+        p = run_cli(tmp_path, case["cfg"])
         assert p.returncode == 0, p.stderr
-        got_res = open(tmp_path / "results.txt").read().split("\n")
-        got_err = open(tmp_path / "new_experiments_errors.txt").read().split("\n")
+        got_res, got_err = outputs(tmp_path)
         assert got_res == res * run + [""]
         assert got_err == err * run + [""]
     assert "True: " in p.stdout and "Starting optimization" in p.stdout
@@ -141,6 +183,66 @@ def test_cli_end_to_end(tmp_path, ccal, oracle, gpu_opt):
     want = [float(v) for v in res[6].split(", ")]
     np.testing.assert_allclose(got, want, rtol=1e-5)
     assert "<gd_max_iterations>12</gd_max_iterations>" in refined
+
+
+def test_cli_text_formats_millimetres_and_degrees(tmp_path, oracle):
+    """ascii PLY, ascii PCD and .xyz clouds in millimetres (helpers.cpp:159-201), the initial pose in
+    millimetres and non-integer degrees (getTransVector :70-98 through degreeToRadian(int),
+    helpers.hpp:275-278: truncated to whole degrees, pi = 3.141592): both files text-identical to the oracle."""
+    case = build_case(tmp_path, text_formats=True, n_points=6000)
+    pose0 = oracle.parse_pose_csv(case["value"], scale=1000.0, degree=True)
+    assert all(abs(v * 180 / 3.141592 - round(v * 180 / 3.141592)) < 1e-9 for v in pose0[3:])   # whole degrees
+    res, err, _ = oracle_expected(oracle, case)
+    p = run_cli(tmp_path, case["cfg"])
+    assert p.returncode == 0, p.stderr
+    got_res, got_err = outputs(tmp_path)
+    assert got_res == res + [""]
+    assert got_err == err + [""]
+
+
+def test_cli_several_contexts_equal_one(tmp_path, oracle):
+    """<device><gpus>3</gpus><share>1</share></device>: three contexts (one host thread each) on the GPUs
+    present, the grid cut into three ranges, shard results merged.  The grid repeats every candidate 27 times
+    (zero rotation step) and the cuts fall inside such runs, so the merge has to keep the lowest index of a
+    tie that spans two shards.  Output must be the single-context run's, which is the oracle's."""
+    search = ("<translation_mm><min>-8</min><step>4</step><count>5</count></translation_mm>"
+              "<rotation_deg><min>0</min><step>0</step><count>3</count></rotation_deg>")
+    grid = ([-8] * 3 + [0] * 3, [4] * 3 + [0] * 3, [5, 5, 5, 3, 3, 3])
+    one = tmp_path / "one"
+    three = tmp_path / "three"
+    os.makedirs(one)
+    os.makedirs(three)
+    c1 = build_case(one, search_xml=search, n_points=8000)
+    c3 = build_case(three, search_xml=search, device_xml="<device><gpus>3</gpus><share>1</share></device>", n_points=8000)
+    res, err, _ = oracle_expected(oracle, c1, grid)
+    for d, c in ((one, c1), (three, c3)):
+        p = run_cli(d, c["cfg"])
+        assert p.returncode == 0, p.stderr
+    r1, e1 = outputs(one)
+    r3, e3 = outputs(three)
+    assert r1 == res + [""] and e1 == err + [""]
+    assert r3[1:] == r1[1:] and e3[1:] == e1[1:]             # line 0 names the config file
+    # without <share> the context count is capped at the GPUs present: still the same answer
+    (three / "results.txt").unlink()
+    (three / "new_experiments_errors.txt").unlink()
+    cfg = open(c3["cfg"]).read().replace("<share>1</share>", "")
+    open(c3["cfg"], "w").write(cfg)
+    assert run_cli(three, c3["cfg"]).returncode == 0
+    assert outputs(three)[0][1:] == r1[1:]
+
+
+def test_cli_one_process_per_gpu_exchange(tmp_path, oracle):
+    """The one-process-per-GPU mode of the executable with one process: the (cost, index) record goes
+    through ncclAllGather (rendezvous file written and removed by rank 0) and the run's files are unchanged."""
+    case = build_case(tmp_path, n_points=8000)
+    res, err, _ = oracle_expected(oracle, case)
+    idfile = tmp_path / "comm.id"
+    p = run_cli(tmp_path, case["cfg"], env={"CCAL_WORLD_SIZE": "1", "CCAL_RANK": "0", "CCAL_COMM_FILE": str(idfile)})
+    assert p.returncode == 0, p.stderr
+    assert outputs(tmp_path) == (res + [""], err + [""])
+    assert not idfile.exists()
+    p = run_cli(tmp_path, case["cfg"], env={"CCAL_WORLD_SIZE": "2", "CCAL_RANK": "0"})
+    assert p.returncode != 0 and "CCAL_COMM_FILE" in p.stderr
 
 
 def test_cli_usage_and_errors(tmp_path):
