@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <limits>
 #include <new>
 #include <thread>
@@ -293,6 +294,20 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     ctx->split_maps.release();
     ctx->split_first.release();
     ctx->static_out.release();
+    {
+        ccal::Staging& S = ctx->staging;
+        if (S.stream) (void)hipStreamSynchronize(S.stream);
+        for (ccal::StageLane& L : S.lanes)
+            for (int k = 0; k < 2; ++k) {
+                L.buf[k].release();
+                if (L.ev[k]) (void)hipEventDestroy(L.ev[k]);
+            }
+        S.lanes.clear();
+        for (hipEvent_t& e : S.batch_ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        S.stream = nullptr;
+    }
     for (hipEvent_t& e : ctx->prof_ev)
         if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -320,6 +335,129 @@ extern "C" void ccal_pose_to_matrix(const double pose[6], double T[16])
 // ---------------------------------------------------------------------------
 // upload
 // ---------------------------------------------------------------------------
+
+// The caller's clouds (pageable memory, one array per cloud) into one device AoS array, and from
+// there -- batch of clouds by batch -- centres, SoA arrays and centred groups (`tile_batch`).
+//   small sets: one copy call per cloud on the context's stream, then all clouds as one batch;
+//   large sets: the byte stream of all clouds is cut into chunks.  A few host threads take chunks in
+//               turn, copy them into pinned buffers of their own and hand each to ONE copy stream
+//               (asynchronous copy + an event that frees the buffer), so the host-side copies of
+//               several threads and the DMA of finished chunks overlap -- a copy call on pageable
+//               memory does both steps one after the other inside the runtime (20 GB/s).  The calling
+//               thread follows the chunks as they are handed over: once all chunks of a batch of clouds
+//               are on the copy stream it lets the context's stream wait for them and enqueues that
+//               batch's kernels, which then run while the next batch is still arriving.
+//               Pinned buffers, the copy stream and the events stay with the context.
+constexpr size_t kStageChunk = (size_t)8 << 20;
+constexpr size_t kStageThreshold = (size_t)192 << 20;
+constexpr int kStageLanes = 8;
+constexpr int kStageBatches = 8;
+
+template <typename TileBatch>
+static hipError_t stage_clouds(ccal_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_pts,
+                               const std::vector<int64_t>& pt_off, float* stage, TileBatch tile_batch)
+{
+    const size_t total_bytes = (size_t)pt_off[n_clouds] * 3 * sizeof(float);
+    if (total_bytes < kStageThreshold) {
+        for (int j = 0; j < n_clouds; ++j) {
+            hipError_t e = hipMemcpyAsync(stage + 3 * (size_t)pt_off[j], xyz[j], n_pts[j] * 3 * sizeof(float),
+                                          hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) return e;
+        }
+        tile_batch(0, n_clouds);
+        return hipSuccess;
+    }
+    const size_t n_chunks = (total_bytes + kStageChunk - 1) / kStageChunk;
+    const int n_lanes = (int)std::min<size_t>({(size_t)kStageLanes, n_chunks, std::max(1u, std::thread::hardware_concurrency())});
+    Staging& S = ctx->staging;
+    if (!S.stream) {
+        hipError_t e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        for (int b = 0; b < kStageBatches && e == hipSuccess; ++b)
+            e = hipEventCreateWithFlags(&S.batch_ev[b], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    if ((int)S.lanes.size() < n_lanes) S.lanes.resize(n_lanes);
+    for (int t = 0; t < n_lanes; ++t) {
+        StageLane& L = S.lanes[t];
+        for (int k = 0; k < 2; ++k) {
+            if (L.ev[k]) continue;
+            hipError_t e = L.buf[k].ensure(kStageChunk);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+    }
+    // batches: runs of whole clouds of about total / kStageBatches bytes; batch b is complete once every
+    // chunk below last_chunk[b] is on the copy stream
+    std::vector<size_t> byte_off(n_clouds + 1);
+    for (int j = 0; j <= n_clouds; ++j) byte_off[j] = (size_t)pt_off[j] * 3 * sizeof(float);
+    std::vector<int> batch_end;          // exclusive cloud index
+    std::vector<size_t> batch_chunks;    // chunks that must have been handed over
+    {
+        const size_t want = std::max<size_t>(4 * kStageChunk, total_bytes / kStageBatches);
+        int j0 = 0;
+        while (j0 < n_clouds) {
+            int j1 = j0 + 1;
+            while (j1 < n_clouds && byte_off[j1] - byte_off[j0] < want && (int)batch_end.size() < kStageBatches - 1) ++j1;
+            if ((int)batch_end.size() == kStageBatches - 1) j1 = n_clouds;
+            batch_end.push_back(j1);
+            batch_chunks.push_back((byte_off[j1] + kStageChunk - 1) / kStageChunk);
+            j0 = j1;
+        }
+    }
+    std::vector<std::atomic<unsigned char>> handed(n_chunks);
+    for (auto& h : handed) h.store(0, std::memory_order_relaxed);
+    std::atomic<size_t> next_chunk{0};
+    std::atomic<int> failed{0};
+    std::vector<hipError_t> errs(n_lanes, hipSuccess);
+    auto work = [&](int t) {
+        StageLane& L = S.lanes[t];
+        hipError_t e = hipSetDevice(ctx->device);
+        int slot = 0;
+        for (size_t c = next_chunk++; c < n_chunks && e == hipSuccess && !failed.load(); c = next_chunk++) {
+            const size_t b = c * kStageChunk, len = std::min(kStageChunk, total_bytes - b);
+            if (L.pending[slot]) e = hipEventSynchronize(L.ev[slot]);   // the buffer's previous copy has left it
+            if (e != hipSuccess) break;
+            L.pending[slot] = false;
+            char* dst = L.buf[slot].as<char>();
+            int j = (int)(std::upper_bound(byte_off.begin(), byte_off.end(), b) - byte_off.begin()) - 1;
+            for (size_t done = 0; done < len; ++j) {
+                const size_t in_cloud = b + done - byte_off[j];
+                const size_t n = std::min(len - done, byte_off[j + 1] - byte_off[j] - in_cloud);
+                std::memcpy(dst + done, reinterpret_cast<const char*>(xyz[j]) + in_cloud, n);
+                done += n;
+            }
+            e = hipMemcpyAsync(reinterpret_cast<char*>(stage) + b, dst, len, hipMemcpyHostToDevice, S.stream);
+            if (e == hipSuccess) e = hipEventRecord(L.ev[slot], S.stream);
+            L.pending[slot] = e == hipSuccess;
+            slot ^= 1;
+            handed[c].store(1, std::memory_order_release);
+        }
+        if (e != hipSuccess) failed.store(1);
+        errs[t] = e;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_lanes; ++t) pool.emplace_back(work, t);
+    hipError_t e = hipSuccess;
+    size_t seen = 0;
+    int j0 = 0;
+    for (size_t b = 0; b < batch_end.size() && e == hipSuccess; ++b) {
+        while (seen < batch_chunks[b] && !failed.load()) {
+            if (handed[seen].load(std::memory_order_acquire)) ++seen;
+            else std::this_thread::yield();
+        }
+        if (failed.load()) break;
+        // the copy stream is in order: an event recorded now follows every chunk handed over so far
+        e = hipEventRecord(S.batch_ev[b], S.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, S.batch_ev[b], 0);
+        if (e == hipSuccess) tile_batch(j0, batch_end[b]);
+        j0 = batch_end[b];
+    }
+    if (e != hipSuccess) failed.store(1);
+    for (auto& th : pool) th.join();
+    for (hipError_t le : errs)
+        if (le != hipSuccess) return le;
+    return e;
+}
 
 extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                                   const float* const* xyz, const size_t* n_pts,
@@ -388,24 +526,10 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     cs.n_groups = n_groups;
     cs.n_pad_points = n_groups * kGroupPoints - (int64_t)total;
 
-    // ---- host: centre of every cloud (FP64 sum in point order) and its weight --------------
     std::vector<double> scale(n_clouds);
-    parallel_over(n_clouds, [&](int j) {
-        const float* p = xyz[j];
-        const size_t n = n_pts[j];
-        double c[3] = {0, 0, 0};
-        for (size_t i = 0; i < n; ++i) {
-            c[0] += p[3 * i]; c[1] += p[3 * i + 1]; c[2] += p[3 * i + 2];
-        }
-        for (int k = 0; k < 3; ++k) {
-            c[k] /= (double)n;
-            if (!std::isfinite(c[k])) c[k] = 0.0;
-            cs.centres[3 * j + k] = c[k];
-        }
-        scale[j] = 1.0 / ((double)n_clouds * (double)n);
-    });
+    for (int j = 0; j < n_clouds; ++j) scale[j] = 1.0 / ((double)n_clouds * (double)n_pts[j]);
 
-    // ---- device: one copy of the caller's AoS clouds, both layouts written from it ----------
+    // ---- device: one copy of the caller's AoS clouds, centres and both layouts made from it ------
     CCAL_HIP(ctx, cs.xs.ensure(total * sizeof(float)));
     CCAL_HIP(ctx, cs.ys.ensure(total * sizeof(float)));
     CCAL_HIP(ctx, cs.zs.ensure(total * sizeof(float)));
@@ -413,26 +537,46 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, hipMemsetAsync(cs.groups.p, 0, (size_t)n_groups * 256 * sizeof(float), ctx->stream));
     CCAL_HIP(ctx, cs.radius_dev.ensure(n_clouds * sizeof(unsigned int)));
     CCAL_HIP(ctx, hipMemsetAsync(cs.radius_dev.p, 0, n_clouds * sizeof(unsigned int), ctx->stream));
+    CCAL_HIP(ctx, cs.cloud_pt_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
+    CCAL_HIP(ctx, hipMemcpyAsync(cs.cloud_pt_off_dev.p, pt_off.data(), (n_clouds + 1) * sizeof(int64_t),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    CCAL_HIP(ctx, cs.centres_dev.ensure(3 * n_clouds * sizeof(double)));
     std::vector<unsigned int> radius2_bits(n_clouds, 0u);
     std::vector<size_t> rblock_off(n_clouds + 1, 0);
     for (int j = 0; j < n_clouds; ++j) rblock_off[j + 1] = rblock_off[j] + (n_pts[j] + 255) / 256;
     std::vector<float> radius_sums(rblock_off[n_clouds], 0.f);
     DevBuf radius_sums_dev;   // per tiling block: sum of its points' distances from the centre
+    const bool trace_upload = std::getenv("CCAL_TRACE_UPLOAD") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tr0 = now();
+    double tr1 = 0, tr2 = 0, tr3 = 0;
     {
-        DevBuf stage;   // the AoS copy lives only for this call
+        DevBuf stage, centre_part;   // the AoS copy lives only for this call
         hipError_t e = stage.ensure(total * 3 * sizeof(float));
         if (e == hipSuccess) e = radius_sums_dev.ensure(radius_sums.size() * sizeof(float));
-        for (int j = 0; j < n_clouds && e == hipSuccess; ++j) {
-            float* dst = stage.as<float>() + 3 * (size_t)pt_off[j];
-            e = hipMemcpyAsync(dst, xyz[j], n_pts[j] * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-            if (e != hipSuccess) break;
-            hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
-                               dst, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j], cs.centres[3 * j],
-                               cs.centres[3 * j + 1], cs.centres[3 * j + 2], cs.xs.as<float>(), cs.ys.as<float>(),
-                               cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j,
-                               radius_sums_dev.as<float>() + rblock_off[j]);
-        }
+        if (e == hipSuccess) e = centre_part.ensure((size_t)n_clouds * kCentreParts * 3 * sizeof(double));
+        tr1 = now();
+        auto tile_batch = [&](int j0, int j1) {
+            hipLaunchKernelGGL(centre_partial_kernel, dim3(kCentreParts, j1 - j0), dim3(256), 0, ctx->stream,
+                               stage.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(), j0, centre_part.as<double>());
+            hipLaunchKernelGGL(centre_final_kernel, dim3((3 * (j1 - j0) + 255) / 256), dim3(256), 0, ctx->stream,
+                               centre_part.as<double>(), cs.cloud_pt_off_dev.as<int64_t>(), j0, j1,
+                               cs.centres_dev.as<double>());
+            for (int j = j0; j < j1; ++j) {
+                const float* src = stage.as<float>() + 3 * (size_t)pt_off[j];
+                hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   src, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j],
+                                   cs.centres_dev.as<double>() + 3 * (size_t)j, cs.xs.as<float>(), cs.ys.as<float>(),
+                                   cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j,
+                                   radius_sums_dev.as<float>() + rblock_off[j]);
+            }
+        };
+        if (e == hipSuccess) e = stage_clouds(ctx, n_clouds, xyz, n_pts, pt_off, stage.as<float>(), tile_batch);
+        tr2 = now();
         if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(cs.centres.data(), cs.centres_dev.p, 3 * (size_t)n_clouds * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(radius2_bits.data(), cs.radius_dev.p, n_clouds * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, ctx->stream);
@@ -440,23 +584,24 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             e = hipMemcpyAsync(radius_sums.data(), radius_sums_dev.p, radius_sums.size() * sizeof(float),
                                hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        tr3 = now();
         stage.release();
+        centre_part.release();
         radius_sums_dev.release();
+        if (trace_upload)
+            std::fprintf(stderr, "upload: alloc %.2f ms, staging %.2f ms, drain %.2f ms, free %.2f ms\n", tr1 - tr0, tr2 - tr1,
+                         tr3 - tr2, now() - tr3);
         CCAL_HIP(ctx, e);
     }
     CCAL_HIP(ctx, cs.blocks.ensure(blocks.size() * sizeof(BlockDesc)));
     CCAL_HIP(ctx, cs.cloud_block_off_dev.ensure((n_clouds + 1) * sizeof(int)));
-    CCAL_HIP(ctx, cs.cloud_pt_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
     CCAL_HIP(ctx, cs.group_off_dev.ensure((n_clouds + 1) * sizeof(int)));
     CCAL_HIP(ctx, cs.scale_dev.ensure(n_clouds * sizeof(double)));
-    CCAL_HIP(ctx, cs.centres_dev.ensure(3 * n_clouds * sizeof(double)));
     CCAL_HIP(ctx, cs.base_dev.ensure(16 * (size_t)n_clouds * sizeof(double)));
     CCAL_HIP(ctx, hipMemcpy(cs.blocks.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.cloud_block_off_dev.p, cs.cloud_block_off.data(),
                             (n_clouds + 1) * sizeof(int), hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.cloud_pt_off_dev.p, pt_off.data(), (n_clouds + 1) * sizeof(int64_t),
-                            hipMemcpyHostToDevice));
     CCAL_HIP(ctx, cs.cloud_seg_off_dev.ensure((n_clouds + 1) * sizeof(int64_t)));
     CCAL_HIP(ctx, hipMemcpy(cs.cloud_seg_off_dev.p, seg_off.data(), (n_clouds + 1) * sizeof(int64_t),
                             hipMemcpyHostToDevice));
@@ -498,8 +643,6 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     CCAL_HIP(ctx, hipMemcpy(cs.group_off_dev.p, cs.group_off.data(), (n_clouds + 1) * sizeof(int),
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.scale_dev.p, scale.data(), n_clouds * sizeof(double),
-                            hipMemcpyHostToDevice));
-    CCAL_HIP(ctx, hipMemcpy(cs.centres_dev.p, cs.centres.data(), 3 * n_clouds * sizeof(double),
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.base_dev.p, cs.base_T_flange.data(),
                             16 * (size_t)n_clouds * sizeof(double), hipMemcpyHostToDevice));

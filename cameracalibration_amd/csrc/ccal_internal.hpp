@@ -59,6 +59,21 @@ struct HostBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Large uploads: every copying host thread owns a lane (a pinned double buffer and the events that say
+// when a buffer's copy has left it); all lanes feed one copy stream; one event per batch of clouds
+// tells the context's stream that the batch has arrived.
+struct StageLane {
+    HostBuf buf[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};   // a copy out of buf[k] was enqueued and not yet waited for
+};
+
+struct Staging {
+    hipStream_t stream = nullptr;
+    hipEvent_t batch_ev[8] = {};
+    std::vector<StageLane> lanes;
+};
+
 struct CloudSet {
     bool ready = false;
     int n_clouds = 0;
@@ -124,6 +139,7 @@ struct ccal_ctx {
     ccal::HostBuf screen_in, screen_out; // four-vectors and per-(pose, cloud) sums of the screening pass
     ccal::DevBuf screen_partial, screen_w;
     bool gd_screening = true;            // line-search trials are first screened on the fast path
+    ccal::Staging staging;               // pinned staging of large uploads (made at the first one, kept)
     bool profiling = false;              // HIP events around the exact and screening kernels
     hipEvent_t prof_ev[3] = {nullptr, nullptr, nullptr};
     ccal_profile prof = {};

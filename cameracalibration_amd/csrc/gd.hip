@@ -222,10 +222,32 @@ struct Machine {
         }
     }
 
+    // a.b the way Eigen sums it for the VectorXd operands gdcpp works on (VectorXd::dot, ::norm,
+    // ::squaredNorm all end in Redux.h's linear vectorised traversal; x86-64 without -march: packets of
+    // two doubles, two packet accumulators, the odd packet added last, then low + high lane).
+    // For n = 6: ((v0 + v2) + v4) + ((v1 + v3) + v5), v_i = a_i b_i.
     static double dot(const double* a, const double* b, int n)
     {
-        double r = 0.0;
-        for (int i = 0; i < n; ++i) r += a[i] * b[i];
+        if (n < 2) return n == 1 ? a[0] * b[0] : 0.0;
+        const int aligned2 = (n / 4) * 4, aligned = (n / 2) * 2;
+        double lo0 = a[0] * b[0], hi0 = a[1] * b[1];
+        if (aligned > 2) {
+            double lo1 = a[2] * b[2], hi1 = a[3] * b[3];
+            for (int i = 4; i < aligned2; i += 4) {
+                lo0 = lo0 + a[i] * b[i];
+                hi0 = hi0 + a[i + 1] * b[i + 1];
+                lo1 = lo1 + a[i + 2] * b[i + 2];
+                hi1 = hi1 + a[i + 3] * b[i + 3];
+            }
+            lo0 = lo0 + lo1;
+            hi0 = hi0 + hi1;
+            if (aligned > aligned2) {
+                lo0 = lo0 + a[aligned2] * b[aligned2];
+                hi0 = hi0 + a[aligned2 + 1] * b[aligned2 + 1];
+            }
+        }
+        double r = lo0 + hi0;
+        for (int i = aligned; i < n; ++i) r = r + a[i] * b[i];
         return r;
     }
 

@@ -175,8 +175,39 @@ Cloud read_ply(const std::string& filename)
     return out;
 }
 
+// LZF decompression (the codec of PCD "binary_compressed" bodies; format of liblzf 3.x): a control
+// byte below 32 starts a literal run of ctrl + 1 bytes; otherwise the top three bits give a length
+// (7 = one more length byte follows), the low five bits and the next byte a distance, and
+// length + 2 bytes are copied from that far back in the output.  Returns false on a malformed stream.
+static bool lzf_decompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len)
+{
+    size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        const unsigned ctrl = in[ip++];
+        if (ctrl < 32) {
+            const size_t run = ctrl + 1;
+            if (ip + run > in_len || op + run > out_len) return false;
+            std::memcpy(out + op, in + ip, run);
+            ip += run;
+            op += run;
+        } else {
+            size_t len = ctrl >> 5;
+            if (len == 7) {
+                if (ip >= in_len) return false;
+                len += in[ip++];
+            }
+            if (ip >= in_len) return false;
+            const size_t dist = ((size_t)(ctrl & 0x1f) << 8) + in[ip++] + 1;
+            len += 2;
+            if (dist > op || op + len > out_len) return false;
+            for (size_t k = 0; k < len; ++k, ++op) out[op] = out[op - dist];   // ranges may overlap
+        }
+    }
+    return op == out_len;
+}
+
 // ---------------------------------------------------------------------------
-// PCD v0.7 (DATA ascii | binary), generic field table
+// PCD v0.7 (DATA ascii | binary | binary_compressed), generic field table
 // ---------------------------------------------------------------------------
 Cloud read_pcd(const std::string& filename)
 {
@@ -202,6 +233,8 @@ Cloud read_pcd(const std::string& filename)
         else if (key == "DATA" && t.size() > 1) { data = lower(t[1]); break; }
     }
     if (!have_points) points = width * height;
+    else if (width && height && points != width * height)
+        throw std::runtime_error(filename + ": PCD POINTS differs from WIDTH x HEIGHT");
     if (fields.empty() || sizes.size() != fields.size() || types.size() != fields.size())
         throw std::runtime_error(filename + ": malformed PCD header");
     if (counts.empty()) counts.assign(fields.size(), 1);
@@ -244,6 +277,29 @@ Cloud read_pcd(const std::string& filename)
             out.push_back((float)load_scalar(p + offs[ix], sizes[ix], kind_of(ix), swap));
             out.push_back((float)load_scalar(p + offs[iy], sizes[iy], kind_of(iy), swap));
             out.push_back((float)load_scalar(p + offs[iz], sizes[iz], kind_of(iz), swap));
+        }
+    } else if (data == "binary_compressed") {
+        // PCL's writer: uint32 compressed size, uint32 uncompressed size, an LZF stream; the
+        // uncompressed body holds the fields one after the other (all points' values of field 0,
+        // then of field 1, ...), not point records
+        unsigned char sz[8];
+        f.read(reinterpret_cast<char*>(sz), 8);
+        if (f.gcount() != 8) throw std::runtime_error(filename + ": truncated PCD body");
+        auto u32 = [](const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
+        const size_t n_comp = u32(sz), n_raw = u32(sz + 4);
+        if (n_raw != (size_t)rec * points) throw std::runtime_error(filename + ": PCD compressed body has the wrong size");
+        std::vector<unsigned char> comp(n_comp), buf(n_raw);
+        f.read(reinterpret_cast<char*>(comp.data()), (std::streamsize)n_comp);
+        if ((size_t)f.gcount() != n_comp) throw std::runtime_error(filename + ": truncated PCD body");
+        if (!lzf_decompress(comp.data(), n_comp, buf.data(), n_raw))
+            throw std::runtime_error(filename + ": malformed LZF stream in the PCD body");
+        const bool swap = !host_is_little_endian();
+        // field i starts at points * (bytes of the fields before it)
+        auto column = [&](int i, size_t r) { return buf.data() + points * (size_t)offs[i] + r * (size_t)(sizes[i] * counts[i]); };
+        for (size_t r = 0; r < points; ++r) {
+            out.push_back((float)load_scalar(column(ix, r), sizes[ix], kind_of(ix), swap));
+            out.push_back((float)load_scalar(column(iy, r), sizes[iy], kind_of(iy), swap));
+            out.push_back((float)load_scalar(column(iz, r), sizes[iz], kind_of(iz), swap));
         }
     } else {
         throw std::runtime_error(filename + ": unsupported PCD DATA '" + data + "'");

@@ -53,15 +53,60 @@ constexpr int kFlushGroups = 32;  // FP32 partial sums are promoted every 128 ad
 // kernel writes both device layouts from them: the SoA coordinates of the exact
 // path and the centred 64-point groups of the fast path (which must be zero
 // beforehand: padding points stay all zero).  One thread per point.
+// Centre of every cloud from the staged AoS copy: FP64 sums in a fixed order (kCentreParts strided
+// partial sums per cloud, each a fixed wave tree, then added in index order), so the centre -- and with
+// it every fast-path value -- does not depend on how the copy was scheduled.  A non-finite mean
+// becomes 0 (the cloud then carries an infinite radius and no fast-path bound is promised for it).
+constexpr int kCentreParts = 64;
+
+__global__ __launch_bounds__(256) void centre_partial_kernel(const float* __restrict__ aos /* all clouds */,
+                                                             const int64_t* __restrict__ cloud_pt_off, int cloud0,
+                                                             double* __restrict__ part /* [cloud][kCentreParts][3] */)
+{
+    __shared__ double red[4][3];
+    const int j = cloud0 + blockIdx.y;
+    const int64_t b = cloud_pt_off[j], e = cloud_pt_off[j + 1];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = b + (int64_t)blockIdx.x * 256 + threadIdx.x; i < e; i += (int64_t)kCentreParts * 256) {
+        s[0] += (double)aos[3 * i + 0];
+        s[1] += (double)aos[3 * i + 1];
+        s[2] += (double)aos[3 * i + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[((int64_t)j * kCentreParts + blockIdx.x) * 3 + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void centre_final_kernel(const double* __restrict__ part,
+                                                           const int64_t* __restrict__ cloud_pt_off, int cloud0,
+                                                           int cloud1, double* __restrict__ centres /* [cloud][3] */)
+{
+    const int t = 3 * cloud0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * cloud1) return;
+    const int j = t / 3, k = t % 3;
+    double s = 0.0;
+    for (int b = 0; b < kCentreParts; ++b) s += part[((int64_t)j * kCentreParts + b) * 3 + k];
+    s /= (double)(cloud_pt_off[j + 1] - cloud_pt_off[j]);
+    centres[t] = (s - s == 0.0) ? s : 0.0;
+}
+
 __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict__ aos /* this cloud */,
                                                          int64_t n, int64_t first_point, int64_t first_group,
-                                                         double cx, double cy, double cz,
+                                                         const double* __restrict__ centre /* this cloud */,
                                                          float* __restrict__ xs, float* __restrict__ ys,
                                                          float* __restrict__ zs, float* __restrict__ groups,
                                                          unsigned int* __restrict__ radius2_bits /* this cloud */,
                                                          float* __restrict__ radius_sums /* this cloud: one per block */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double cx = centre[0], cy = centre[1], cz = centre[2];
     float r2 = 0.f;
     if (i < n) {
         const float x = aos[3 * i + 0], y = aos[3 * i + 1], z = aos[3 * i + 2];

@@ -473,11 +473,35 @@ static double gd_eval(gd_env* e, const orc_gd_opts* o, const double* x, double* 
     return fval;
 }
 
+/* VectorXd::dot / ::squaredNorm (and ::norm = sqrt of it) as Eigen 3.3 evaluates them: Redux.h,
+ * redux_impl<..., LinearVectorizedTraversal, NoUnrolling> over the coefficient-wise products, SSE2
+ * packets of two doubles on x86-64 without -march:
+ *   p0 = packet(0); p1 = packet(2); for i = 4, 8, ... below alignedEnd2: p0 += packet(i), p1 += packet(i+2);
+ *   p0 += p1; if a whole packet is left: p0 += packet(alignedEnd2); res = p0.lo + p0.hi; then the odd tail.
+ * Eigen's aligned allocation puts a VectorXd's data on a 16-byte boundary, so alignedStart = 0. */
 static double dotn(const double* a, const double* b, int n)
 {
-    double r = 0.0;
-    for (int i = 0; i < n; ++i) r += a[i] * b[i];
-    return r;
+    double v[16];
+    for (int i = 0; i < n; ++i) v[i] = a[i] * b[i];
+    if (n < 2) return n == 1 ? v[0] : 0.0;
+    int packet = 2;
+    int aligned_end2 = (n / (2 * packet)) * (2 * packet);
+    int aligned_end = (n / packet) * packet;
+    double p0[2] = {v[0], v[1]};
+    if (aligned_end > packet) {
+        double p1[2] = {v[2], v[3]};
+        for (int i = 2 * packet; i < aligned_end2; i += 2 * packet) {
+            p0[0] = p0[0] + v[i];     p0[1] = p0[1] + v[i + 1];
+            p1[0] = p1[0] + v[i + 2]; p1[1] = p1[1] + v[i + 3];
+        }
+        p0[0] = p0[0] + p1[0]; p0[1] = p0[1] + p1[1];
+        if (aligned_end > aligned_end2) {
+            p0[0] = p0[0] + v[aligned_end2]; p0[1] = p0[1] + v[aligned_end2 + 1];
+        }
+    }
+    double res = p0[0] + p0[1];
+    for (int i = aligned_end; i < n; ++i) res = res + v[i];
+    return res;
 }
 
 /* gdcpp WolfeBacktracking::operator() */

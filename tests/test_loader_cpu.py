@@ -53,6 +53,58 @@ def write_pcd_ascii(path, pts):
             f.write("%.9g %.9g %.9g\n" % tuple(p))
 
 
+def lzf_compress(data: bytes) -> bytes:
+    """A small LZF encoder for the tests (format of liblzf): runs of a repeated byte become back
+    references of distance 1 (lengths up to 264, so both length encodings occur), everything else literals."""
+    out = bytearray()
+    lit = bytearray()
+
+    def flush():
+        for k in range(0, len(lit), 32):
+            piece = lit[k:k + 32]
+            out.append(len(piece) - 1)
+            out.extend(piece)
+        lit.clear()
+
+    i, n = 0, len(data)
+    while i < n:
+        run = 1
+        while i + run < n and data[i + run] == data[i] and run < 265:
+            run += 1
+        if run >= 4 and (lit or out):                 # a reference needs one byte of history
+            flush()
+            length = run - 1                          # the first byte goes out as a literal below
+            lit.append(data[i])
+            flush()
+            ln = length - 2
+            if ln < 7:
+                out.append(ln << 5)
+            else:
+                out.append(7 << 5)
+                out.append(ln - 7)
+            out.append(0)                             # distance 1
+            i += run
+        else:
+            lit.append(data[i])
+            i += 1
+    flush()
+    return bytes(out)
+
+
+def write_pcd_compressed(path, pts):
+    # field order as PCL writes an XYZRGB cloud; body = the fields one after the other (SoA), LZF-compressed
+    n = len(pts)
+    hdr = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\nTYPE F F F F\n"
+           "COUNT 1 1 1 1\nWIDTH %d\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n" % (n, n))
+    p = pts.astype("<f4")
+    body = p[:, 0].tobytes() + p[:, 1].tobytes() + p[:, 2].tobytes() + np.zeros(n, "<f4").tobytes()
+    comp = lzf_compress(body)
+    with open(path, "wb") as f:
+        f.write(hdr.encode())
+        f.write(struct.pack("<II", len(comp), len(body)))
+        f.write(comp)
+
+
 @pytest.fixture()
 def pts():
     rng = np.random.default_rng(12)
@@ -81,6 +133,24 @@ def test_pcd_readers(ccal, pts, tmp_path):
     np.testing.assert_array_equal(ccal.read_point_cloud(p), pts)
     got = ccal.read_point_cloud(p, "cm")
     np.testing.assert_array_equal(got, (pts.astype(np.float64) / 100.0).astype(np.float32))
+    # binary_compressed (PCL's usual save format): LZF stream over the field-major body
+    q = pts.copy()
+    q[100:400, 1] = 0.25                                     # long runs: back references of both length forms
+    q[500:520, 2] = 0.0
+    write_pcd_compressed(p, q)
+    np.testing.assert_array_equal(ccal.read_point_cloud(p), q)
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:-40])                           # truncated stream
+    with pytest.raises(ccal.CcalError):
+        ccal.read_point_cloud(p)
+    body = raw.index(b"DATA binary_compressed\n") + 23
+    open(p, "wb").write(raw[:body + 8] + bytes([0xE0, 0xFF, 0xFF]) + raw[body + 11:])   # a reference before the start
+    with pytest.raises(ccal.CcalError):
+        ccal.read_point_cloud(p)
+    hdr_bad = raw.replace(b"POINTS %d" % len(q), b"POINTS %d" % (len(q) + 1))
+    open(p, "wb").write(hdr_bad)                             # POINTS != WIDTH x HEIGHT
+    with pytest.raises(ccal.CcalError):
+        ccal.read_point_cloud(p)
 
 
 def test_xyz_reader(ccal, pts, tmp_path):
