@@ -21,16 +21,15 @@
 using namespace ccal;
 
 // Scratch of ccal_fit_plane_lsq_static, the one entry point that allocates nothing: the per-cloud
-// matrices of the pose ([kStaticMaxClouds][12]) followed by the per-block partial moments
-// ([kStaticMaxBlocks][kMoments]).  Every GPU holds its own copy of this array at its own address;
+// matrices of the pose ([kStaticMaxClouds][12]) followed by the partial moments of the moment pass's
+// workgroups ([kMomentGrid][kMoments]).  Every GPU holds its own copy of this array at its own address;
 // host code only ever uses the address hipGetSymbolAddress returned for the context's device
 // (ccal_ctx::static_scratch), never the array's name.  All contexts of one GPU share the copy:
 // calls that overlap on one GPU race.  Nothing in it has to start at zero (a call overwrites
 // every row it reads).
 constexpr int kStaticMaxClouds = 1024;
-constexpr int kStaticMaxBlocks = 32768;     // 4096-point blocks: up to 1.3e8 points
-constexpr size_t kStaticScratchDoubles = (size_t)kStaticMaxClouds * 12 + (size_t)kStaticMaxBlocks * kMoments;
-static __device__ __align__(256) double scratch[kStaticScratchDoubles];   // 2.6 MiB per GPU
+constexpr size_t kStaticScratchDoubles = (size_t)kStaticMaxClouds * 12 + (size_t)kMomentGrid * kMoments;
+static __device__ __align__(256) double scratch[kStaticScratchDoubles];   // 256 KiB per GPU
 
 namespace {
 
@@ -1730,12 +1729,12 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     CCAL_HIP(ctx, ctx->osum_buf.ensure(kMoments * sizeof(double)));
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
                                  hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(moments_kernel, dim3(moment_rows(cs.n_blocks)), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
+                       cs.blocks.as<BlockDesc>(), cs.n_blocks, ctx->mats_buf.as<double>(), org[0], org[1],
                        org[2], InlierMask{{0, 0, 0, 0, 1}, -1.0}, ctx->psum_buf.as<double>());
     hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
+                       ctx->psum_buf.as<double>(), moment_rows(cs.n_blocks), ctx->osum_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
     double m[kMoments];
     CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
@@ -1765,10 +1764,10 @@ extern "C" int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double 
     if (!pose || !plane_out) return fail(ctx, CCAL_ERR_ARG, "fit_plane_lsq_static: null argument");
     const CloudSet& cs = ctx->sets[which];
     const int C = cs.n_clouds;
-    if (C > kStaticMaxClouds || cs.n_blocks > kStaticMaxBlocks)
+    if (C > kStaticMaxClouds)
         return fail(ctx, CCAL_ERR_CAPACITY,
-                    "fit_plane_lsq_static: the set exceeds the static scratch (at most 1024 clouds and 32768 "
-                    "blocks of 4096 points); use ccal_fit_plane_lsq");
+                    "fit_plane_lsq_static: the set exceeds the static scratch (at most 1024 clouds); use "
+                    "ccal_fit_plane_lsq");
     if (int rc = bind(ctx)) return rc;
     // origin for the moments: the first cloud's centre carried to the base frame (as ccal_fit_plane_lsq)
     const SinCos3 sc = sincos_of_pose(pose);
@@ -1784,10 +1783,10 @@ extern "C" int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double 
     double* m = ctx->static_out.as<double>();                         // pinned: the last kernel writes it
     hipLaunchKernelGGL(pose_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, cs.base_dev.as<double>(),
                        C, sc, pose[0], pose[1], pose[2], mats);
-    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.xs.as<float>(),
-                       cs.ys.as<float>(), cs.zs.as<float>(), cs.blocks.as<BlockDesc>(), mats, org[0], org[1], org[2],
+    hipLaunchKernelGGL(moments_kernel, dim3(moment_rows(cs.n_blocks)), dim3(256), 0, ctx->stream, cs.xs.as<float>(),
+                       cs.ys.as<float>(), cs.zs.as<float>(), cs.blocks.as<BlockDesc>(), cs.n_blocks, mats, org[0], org[1], org[2],
                        InlierMask{{0, 0, 0, 0, 1}, -1.0}, part);
-    hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, cs.n_blocks, m);
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, moment_rows(cs.n_blocks), m);
     CCAL_HIP(ctx, hipGetLastError());
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return plane_from_moments(ctx, m, org, plane_out, "fit_plane_lsq_static");

@@ -2034,38 +2034,70 @@ struct InlierMask {
     double thr;
 };
 
+// Workgroups of the moment pass: each takes a contiguous share of the 4096-point block table (a fixed
+// assignment: the partial sums, and so the result, are the same bits on every run).
+constexpr int kMomentGrid = 2048;
+
+__host__ __device__ inline int moment_rows(int n_table) { return n_table < kMomentGrid ? n_table : kMomentGrid; }
+
 __global__ __launch_bounds__(256) void moments_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats, double ox, double oy,
-    double oz, InlierMask mask, double* __restrict__ part)
+    const BlockDesc* __restrict__ blocks, int n_table, const double* __restrict__ mats, double ox, double oy,
+    double oz, InlierMask mask, double* __restrict__ part /* [moment_rows(n_table)][kMoments] */)
 {
     __shared__ double sM[12];
     __shared__ double red[4][kMoments];
-    const BlockDesc bd = blocks[blockIdx.x];
-    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
-    __syncthreads();
+    const int rows = moment_rows(n_table);
+    const int t0 = (int)((int64_t)n_table * blockIdx.x / rows), t1 = (int)((int64_t)n_table * (blockIdx.x + 1) / rows);
     double m[kMoments];
 #pragma unroll
     for (int k = 0; k < kMoments; ++k) m[k] = 0.0;
-    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
-        const double xd = (double)xs[i], yd = (double)ys[i], zd = (double)zs[i];
-        float q[3];
+    int cloud = -1;
+    for (int t = t0; t < t1; ++t) {
+        const BlockDesc bd = blocks[t];
+        if (bd.cloud != cloud) {             // uniform over the workgroup
+            __syncthreads();
+            if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+            __syncthreads();
+            cloud = bd.cloud;
+        }
+        // four points per thread and trip: their twelve loads are in flight together (the pass is bound by
+        // HBM and FP64 issue about equally).  The transform keeps the reference's operation order (the point
+        // must be the float the optimiser sees); the moment sums are fused multiply-adds -- any order and
+        // rounding of these sums is as good as another, only the fixed order matters.
+        constexpr int kPer = 4;
+        for (int64_t i0 = bd.begin + threadIdx.x; i0 < bd.end; i0 += (int64_t)kPer * blockDim.x) {
+            float X[kPer], Y[kPer], Z[kPer];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            double p = sM[r * 4 + 3];
-            p = xd * sM[r * 4 + 0] + p;
-            p = yd * sM[r * 4 + 1] + p;
-            p = zd * sM[r * 4 + 2] + p;
-            q[r] = (float)p;
+            for (int u = 0; u < kPer; ++u) {
+                const int64_t i = i0 + (int64_t)u * blockDim.x;
+                const int64_t ic = i < bd.end ? i : bd.begin;
+                X[u] = xs[ic]; Y[u] = ys[ic]; Z[u] = zs[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                if (i0 + (int64_t)u * blockDim.x >= bd.end) continue;
+                const double xd = (double)X[u], yd = (double)Y[u], zd = (double)Z[u];
+                float q[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double p = sM[r * 4 + 3];
+                    p = xd * sM[r * 4 + 0] + p;
+                    p = yd * sM[r * 4 + 1] + p;
+                    p = zd * sM[r * 4 + 2] + p;
+                    q[r] = (float)p;
+                }
+                if (mask.thr >= 0.0) {
+                    const double num = mask.pl[0] * (double)q[0] + mask.pl[1] * (double)q[1] +
+                                       mask.pl[2] * (double)q[2] + mask.pl[3];
+                    if (!(__builtin_fabs(num) / mask.pl[4] < mask.thr)) continue;
+                }
+                const double x = (double)q[0] - ox, y = (double)q[1] - oy, z = (double)q[2] - oz;
+                m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+                m[4] = __builtin_fma(x, x, m[4]); m[5] = __builtin_fma(x, y, m[5]); m[6] = __builtin_fma(y, y, m[6]);
+                m[7] = __builtin_fma(x, z, m[7]); m[8] = __builtin_fma(y, z, m[8]); m[9] = __builtin_fma(z, z, m[9]);
+            }
         }
-        if (mask.thr >= 0.0) {
-            const double num = mask.pl[0] * (double)q[0] + mask.pl[1] * (double)q[1] +
-                               mask.pl[2] * (double)q[2] + mask.pl[3];
-            if (!(__builtin_fabs(num) / mask.pl[4] < mask.thr)) continue;
-        }
-        const double x = (double)q[0] - ox, y = (double)q[1] - oy, z = (double)q[2] - oz;
-        m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
-        m[4] += x * x; m[5] += x * y; m[6] += y * y; m[7] += x * z; m[8] += y * z; m[9] += z * z;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll

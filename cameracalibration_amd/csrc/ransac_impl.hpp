@@ -174,12 +174,12 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                  mats[r * 4 + 2] * cs.centres[2] + mats[r * 4 + 3];
     CCAL_HIP(ctx, ctx->psum_buf.ensure((size_t)cs.n_blocks * kMoments * sizeof(double)));
     CCAL_HIP(ctx, ctx->osum_buf.ensure(kMoments * sizeof(double)));
-    hipLaunchKernelGGL(moments_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(moments_kernel, dim3(moment_rows(cs.n_blocks)), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(), org[0], org[1],
+                       cs.blocks.as<BlockDesc>(), cs.n_blocks, ctx->mats_buf.as<double>(), org[0], org[1],
                        org[2], mask, ctx->psum_buf.as<double>());
     hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->psum_buf.as<double>(), cs.n_blocks, ctx->osum_buf.as<double>());
+                       ctx->psum_buf.as<double>(), moment_rows(cs.n_blocks), ctx->osum_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
     double m[kMoments];
     CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));

@@ -242,12 +242,12 @@ int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6], float pla
 
 /* ccal_fit_plane_lsq for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same inputs, same result bit for bit; the per-cloud matrices and the per-block
- * partial moments live in a static device array of the library (2.6 MiB per GPU, held until the
- * process ends) instead of grow-only buffers, and the call issues kernel launches and one stream
- * wait only -- no hipMalloc / hipFree / copy call.  Limits: at most 1024 clouds and 32768 blocks
- * of 4096 points (about 1.3e8 points) in the set, else CCAL_ERR_CAPACITY.  All contexts of one
- * GPU share that array: calls that overlap on one GPU race. */
+ * reference.  Same inputs, same result bit for bit; the per-cloud matrices and the partial
+ * moments of the pass's workgroups live in a static device array of the library (256 KiB per
+ * GPU, held until the process ends) instead of grow-only buffers, and the call issues kernel
+ * launches and one stream wait only -- no hipMalloc / hipFree / copy call.  Limit: at most 1024
+ * clouds in the set (any number of points), else CCAL_ERR_CAPACITY.  All contexts of one GPU
+ * share that array: calls that overlap on one GPU race. */
 int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double pose[6], float plane_out[4]);
 
 /* RANSAC plane with the parameters of getPlane (cloud_analyzer.cpp:103-121:
