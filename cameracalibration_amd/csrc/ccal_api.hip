@@ -281,7 +281,7 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
                       &ctx->minrec_buf, &ctx->list_buf, &ctx->count_buf, &ctx->mats_buf,
                       &ctx->planes_buf, &ctx->psum_buf, &ctx->osum_buf,
                       &ctx->omax_buf, &ctx->tbl_buf, &ctx->dist_buf, &ctx->sep_wr,
-                      &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta};
+                      &ctx->sep_sb, &ctx->sep_perm, &ctx->sep_tab, &ctx->sep_meta, &ctx->sep_wcnt, &ctx->sep_wsum};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->vox) b.release();
     ctx->exact_in.release();
@@ -1167,19 +1167,35 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
 // ---------------------------------------------------------------------------
 // separable search: all translations of a rotation from one pass over the points
 // ---------------------------------------------------------------------------
-// Translations per launch (histogram bins in LDS) x rotations per workgroup: 1024 x 2 when one
-// launch holds all translations (37 KB of LDS; 2 rotations measured 10 % faster than 4 or 8);
-// 2048 x 2 for longer lists, which halves the number of passes over the points (74 KB).
+// Translations per launch (histogram bins in LDS, 8 bytes each) x rotations per workgroup: 1024 x 4
+// when one launch holds all translations (53 KB of LDS: three workgroups per CU); 2048 x 2 for longer
+// lists, which halves the number of launches (57 KB).
+// Scale of the separable pass's fixed point for residuals bounded by vmax: the largest power of two with
+// vmax * scale < 2^31 (capped at 2^40; 1 for a non-finite bound, which the pass is never run with).
+static double separable_fx_scale(double vmax)
+{
+    if (!std::isfinite(vmax)) return 1.0;
+    int e = 40;
+    while (e > -60 && vmax * std::ldexp(1.0, e) >= 2147483000.0) --e;
+    return std::ldexp(1.0, e);
+}
+
 constexpr int kSepBucketsShort = 8, kSepBucketsLong = 4;   // lookup-table buckets per bin (LDS: 16 KB either way)
 
 template <int TC, int RB, int BPB>
-static void launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr)
+static hipError_t launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr, float fx_scale)
 {
+    // wide accumulators: one slice of RB x (TC + 1) bins per workgroup
+    const size_t n_wg = (size_t)((nr + RB - 1) / RB) * cs.n_clouds, bins = (size_t)RB * (TC + 1);
+    hipError_t e = ctx->sep_wcnt.ensure(n_wg * bins * sizeof(unsigned int));
+    if (e == hipSuccess) e = ctx->sep_wsum.ensure(n_wg * bins * sizeof(long long));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((separable_hist_kernel<TC, RB, BPB>), dim3((nr + RB - 1) / RB, cs.n_clouds),
                        dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
                        wr, ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(), ctx->sep_tab.as<unsigned short>(),
-                       ctx->sep_meta.as<SepMeta>(), cs.scale_dev.as<double>(), cs.n_clouds, nt, nr,
-                       ctx->partial_buf.as<double>());
+                       ctx->sep_meta.as<SepMeta>(), cs.scale_dev.as<double>(), cs.cloud_pt_off_dev.as<int64_t>(),
+                       cs.n_clouds, nt, nr, fx_scale, ctx->sep_wcnt.as<unsigned int>(), ctx->sep_wsum.as<long long>(), ctx->partial_buf.as<double>());
+    return hipSuccess;
 }
 
 // Fast-path costs of translations [t0, t1) x all R rotations of the grid into
@@ -1219,6 +1235,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 
     // rotation vectors: w123 = R_F^T g_j / |n|, a = w123.c_j + bref_j
     std::vector<float> wr((size_t)R * C * 4);
+    double vmax = 0.0;   // bound on |u| = |w123 . (p - c) + a| over rotations, clouds and points
     {
         std::vector<double> sn[3], cn[3];
         for (int k = 0; k < 3; ++k) {
@@ -1242,6 +1259,8 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
                                  w[2] * cs.centres[3 * j + 2] + bref[j];
                 float* dst = wr.data() + ((size_t)r * C + j) * 4;
                 dst[0] = (float)w[0]; dst[1] = (float)w[1]; dst[2] = (float)w[2]; dst[3] = (float)a;
+                const double wn = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+                vmax = std::max(vmax, (wn * cs.radius[j] + std::fabs(a)) * (1.0 + 1e-5));
             }
         }
     }
@@ -1249,8 +1268,10 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->sep_wr.p, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice,
                                  ctx->stream));
 
+    // fixed point of the histogram sums: the power of two that keeps |u| * fx_scale below 2^31
+    const float fx_scale = (float)separable_fx_scale(vmax);
     const bool long_list = t1 - t0 > 1024;
-    const int tc = long_list ? 2048 : 1024, rb = 2;
+    const int tc = long_list ? 2048 : 1024, rb = long_list ? 2 : 4;
     const int bpb = long_list ? kSepBucketsLong : kSepBucketsShort;
     const int M = bpb * tc;
     std::vector<float> sb;
@@ -1311,8 +1332,9 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             const int nr = (int)std::min<int64_t>(nr_max, R - ra);
             CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
             CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
-            if (long_list) launch_separable<2048, 2, kSepBucketsLong>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
-            else launch_separable<1024, 2, kSepBucketsShort>(ctx, cs, ctx->sep_wr.as<f32x4>() + (size_t)ra * C, nt, nr);
+            const f32x4* wr_dev = ctx->sep_wr.as<f32x4>() + (size_t)ra * C;
+            if (long_list) CCAL_HIP(ctx, (launch_separable<2048, 2, kSepBucketsLong>(ctx, cs, wr_dev, nt, nr, fx_scale)));
+            else CCAL_HIP(ctx, (launch_separable<1024, 4, kSepBucketsShort>(ctx, cs, wr_dev, nt, nr, fx_scale)));
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
                                0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);
@@ -1348,12 +1370,15 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 //                relative 132u of the sum; one more u for the float the cost is stored as.
 //   separable pass: w, p - c, the rotation constant a and the translation constant b rounded to float,
 //                a four-rounding FP32 chain on magnitudes <= rn |p - c| + |a|, 2^-32 m fixed point
-//                (rounding, and the sign taken from the unrounded value): u (6 rn rho + 5 A + B) + 2^-31
+//                (truncation: below one unit; the sign taken from the unrounded value: one more; budgeted as three):
+//                u (6 rn rho + 5 A + B) + 3 units
+//                of the fixed point (a unit = 2^-30 of the largest possible |residual|, rounded up to
+//                a power of two)
 //                with A >= |a| (the carried centre's distance at the middle translation: <= w4 above)
 //                and B = 2 rn |largest translation offset| >= |b - b_ref|; integer sums add nothing.
 // The FP64 arithmetic on both sides is below 1e-12 of these magnitudes; kScreenSlack covers it.
-// separable_ok: the separable kernel keeps residuals in +-64 m of fixed point; false when the box
-// cannot guarantee |residual| < 64 m for every point (or a point is not finite).
+// separable_ok: false when no finite bound on the residuals exists (a non-finite point, a
+// non-finite robot matrix): the histogram pass needs one for its fixed point.
 struct GridBudget {
     double abs_err = 0.0, rel_err = 0.0;
     bool separable_ok = true;
@@ -1402,10 +1427,11 @@ static GridBudget grid_budget(const ccal_ctx* ctx, const CloudSet& cs, const dou
         double budget;
         if (separable) {
             const double span = 2.0 * rn * T;
-            budget = u24 * ex + u24 * (6.0 * rn * rho + 5.0 * w4max + span) + 0x1p-31;
-            // largest |residual| the histogram pass can meet: rotation part + constant, translation excluded
-            const double vmax = rn * cs.radius[j] + w4max;
-            if (!(vmax < 60.0)) gb.separable_ok = false;
+            // largest |residual| the histogram pass can meet: rotation part + constant, translation excluded;
+            // its fixed point rounds by half a unit and takes the sign from the unrounded value (one more unit)
+            const double vmax = (rn * cs.radius[j] + w4max) * (1.0 + 1e-5);
+            if (!(vmax < 1e12)) gb.separable_ok = false;
+            budget = u24 * ex + u24 * (6.0 * rn * rho + 5.0 * w4max + span) + 3.0 / separable_fx_scale(vmax);
         } else {
             budget = u24 * ex + k_dense * u24 * (rn * rho + w4max);
         }
@@ -1425,9 +1451,9 @@ static int grid_fast_pass(ccal_ctx* ctx, const CloudSet& cs, const double base_p
     const int64_t n_local = end - begin;
     *kernel_ms = 0.0;
     *launches = 0;
-    // the separable pass keeps 2^-32 m fixed-point sums of up to 64 m per point in 64 bits:
-    // clouds of 2^25 points or more, and scenes whose residuals are not certain to stay inside
-    // +-64 m over the whole grid box, take the dense sweep
+    // the separable pass sums 32-bit fixed-point residuals in 64 bits and counts in 32: clouds of 2^25
+    // points or more, and scenes without a finite bound on the residuals over the grid box (its fixed
+    // point is laid out from that bound), take the dense sweep
     bool separable = ctx->search_mode == CCAL_SEARCH_SEPARABLE;
     for (size_t n : cs.n_pts) separable = separable && n < ((size_t)1 << 25);
     if (separable) {

@@ -129,7 +129,7 @@ struct ccal_ctx {
 
     // scratch (grow-only)
     ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
-    ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta;
+    ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta, sep_wcnt, sep_wsum;
     ccal::DevBuf vox[13];                // scratch of the device voxel grid
     ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
     ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation

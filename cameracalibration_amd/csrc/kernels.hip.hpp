@@ -19,6 +19,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "pose_math.hpp"
@@ -992,6 +993,25 @@ constexpr unsigned kSepRankBits = 12, kSepRankMask = (1u << kSepRankBits) - 1u;
 
 // BPB = buckets of the lookup table per histogram bin: with several the typical bucket holds no
 // threshold or one, so the rank of a key is the table entry plus one or two comparisons.
+//
+// Fixed point: u * fx_scale rounded to a 32-bit integer (fx_scale = a power of two chosen by the
+// caller so that |u| * fx_scale < 2^31 over the whole grid; the conversion saturates, so a wrong
+// bound can only saturate values).  At least 2^-30 of the largest |u|: finer than the float u itself
+// for all but the smallest residuals.
+//
+// A bin is ONE 64-bit word in LDS: count in the top 16 bits, the sum of the biased values (fixed point
+// + 2^31, below 2^32) in the low 48, so a point costs one LDS atomic.  The word holds 65535 points
+// without a carry into the count; every kSepFlushTrips trips of the point loop (2048 points per trip)
+// the workgroup empties its words into wide (32-bit count, 64-bit sum) accumulators in global memory
+// -- its own slice, touched a handful of times per cloud, L2-resident.  With 8 bytes of LDS per bin a
+// workgroup can serve RB = 4 rotations from one pass over the cloud's points (the pass is bound by the
+// rate at which the points come out of L2: 16 bytes per point and workgroup).
+//
+// The point loop works on all 4 points x RB rotations of a trip at once, phase by phase (values and
+// table reads; threshold reads; the rare crowded buckets; atomics), so that the LDS reads of a trip
+// are in flight together instead of one round trip per item.
+constexpr int kSepFlushTrips = 31;   // 31 * 2048 = 63488 points < 65536
+
 template <int TC, int RB, int BPB>
 __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off,
@@ -1001,100 +1021,192 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     const unsigned short* __restrict__ tab,  // [cloud][M + 1]: see kSepRankBits; entry [M] = nt
     const SepMeta* __restrict__ meta,        // [cloud]
     const double* __restrict__ scale,        // [cloud]: 1 / (n_clouds * n_points)
-    int n_clouds, int nt, int nr, double* __restrict__ partial /* [cloud][nt][nr] */)
+    const int64_t* __restrict__ cloud_pt_off,
+    int n_clouds, int nt, int nr, float fx_scale,
+    unsigned int* __restrict__ wide_cnt, long long* __restrict__ wide_sum,   // [workgroup][RB][TC + 1]
+    double* __restrict__ partial /* [cloud][nt][nr] */)
 {
     constexpr int M = BPB * TC;
-    constexpr unsigned long long kMagicBits = 0x4138000000000000ull;   // 1.5 * 2^20
-    __shared__ unsigned int cnt[RB][TC + 1];
-    __shared__ unsigned long long sum[RB][TC + 1];
-    __shared__ float sbs[TC];
+    constexpr int kBins = RB * (TC + 1);
+    __shared__ unsigned long long pk[RB][TC + 1];
+    __shared__ float sbs[TC + 1];          // [nt] = +infinity
     __shared__ unsigned short tabs[M + 2];
+    __shared__ unsigned long long tot_c[RB];
+    __shared__ long long tot_s[RB], tot_all_s[RB];
     const int j = blockIdx.y;
     const int r0 = blockIdx.x * RB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kWaves = kSepThreads / 64;
+    const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    unsigned int* wcnt = wide_cnt + wg * kBins;
+    long long* wsum = wide_sum + wg * kBins;
 
-    for (int i = threadIdx.x; i < nt; i += kSepThreads) sbs[i] = sb[(int64_t)j * nt + i];
+    for (int i = threadIdx.x; i <= nt; i += kSepThreads) sbs[i] = i < nt ? sb[(int64_t)j * nt + i] : __builtin_inff();
     for (int i = threadIdx.x; i <= M; i += kSepThreads) tabs[i] = tab[(int64_t)j * (M + 1) + i];
-    for (int i = threadIdx.x; i < RB * (TC + 1); i += kSepThreads) {
-        (&cnt[0][0])[i] = 0u;
-        (&sum[0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < kBins; i += kSepThreads) {
+        (&pk[0][0])[i] = 0ull;
+        wcnt[i] = 0u;          // thread t owns bins t, t + kSepThreads, ... in every pass over them
+        wsum[i] = 0ll;
     }
-    f32x4 w[RB];
+    if (threadIdx.x < RB) tot_all_s[threadIdx.x] = 0ll;
+    // rotation vectors in pairs: the residuals of two rotations of one point are one packed FP32 chain
+    static_assert(RB % 2 == 0, "rotations are handled in pairs");
+    f32x2 w0[RB / 2], w1[RB / 2], w2[RB / 2], w3[RB / 2];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int r = r0 + rb < nr ? r0 + rb : nr - 1;   // a partial last group repeats its last rotation
-        w[rb] = wr[(int64_t)r * n_clouds + j];
+    for (int rp = 0; rp < RB / 2; ++rp) {
+        const int ra = r0 + 2 * rp < nr ? r0 + 2 * rp : nr - 1;       // a partial last group repeats its last rotation
+        const int rc = r0 + 2 * rp + 1 < nr ? r0 + 2 * rp + 1 : nr - 1;
+        const f32x4 a = wr[(int64_t)ra * n_clouds + j], c = wr[(int64_t)rc * n_clouds + j];
+        w0[rp] = f32x2{a[0], c[0]}; w1[rp] = f32x2{a[1], c[1]}; w2[rp] = f32x2{a[2], c[2]}; w3[rp] = f32x2{a[3], c[3]};
     }
+    const f32x2 fx2 = {fx_scale, fx_scale};
     const SepMeta mt = meta[j];
-    unsigned c_lo[RB] = {}, c_hi[RB] = {};
-    unsigned long long s_lo[RB] = {}, s_hi[RB] = {};
+    // The two outer bins (every point beyond the thresholds: most points, for rotations far from the
+    // optimum) never touch LDS.  Their counts are wave-wide population counts (scalar registers); of the
+    // sums a lane keeps the one of ALL its points and the one of the points below the first threshold --
+    // the sum above the last threshold is what is left once the bins in between are known.
+    unsigned c_lo[RB] = {};
+    unsigned long long s_all[RB] = {}, s_lo[RB] = {};
     __syncthreads();
 
-    // points: a wave takes four 64-point groups per trip, a lane the four points of one column
-    const int g0 = group_off[j], g1 = group_off[j + 1];
-    const int col = lane & 15, gsel = lane >> 4;
-    for (int g = g0 + wave * 4 + gsel; g < g1; g += kWaves * 4) {
-        const f32x4* gp = groups + (int64_t)g * 64 + col;
-        const f32x4 x4 = gp[0], y4 = gp[16], z4 = gp[32], o4 = gp[48];
+    auto flush = [&]() {
+        // every bin by the thread that owns it: plain read-modify-write, no atomics
+        for (int i = threadIdx.x; i < kBins; i += kSepThreads) {
+            const unsigned long long p = (&pk[0][0])[i];
+            if (p == 0ull) continue;
+            const unsigned long long c = p >> 48;
+            wcnt[i] += (unsigned int)c;
+            wsum[i] += (long long)(p & 0xffffffffffffull) - (long long)(c << 31);
+            (&pk[0][0])[i] = 0ull;
+        }
+    };
+
+    // One trip of a lane: the four points of its column of group g, all RB rotations, one point (RB items)
+    // at a time and phase by phase, written without branches: flags are integers, every item reads the
+    // table and its bucket's first threshold (an empty bucket's entry is the rank of the NEXT threshold,
+    // which lies in a higher bucket and so above the key: the comparison adds nothing; one past the last
+    // threshold sits +infinity).  kCheck: the group may hold padding points.
+    auto trip = [&](const f32x4* gp, auto check) {
+        constexpr bool kCheck = decltype(check)::value;
+        const f32x4 x4 = gp[0], y4 = gp[16], z4 = gp[32];
+        f32x4 o4 = {1.f, 1.f, 1.f, 1.f};
+        if (kCheck) o4 = gp[48];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (o4[u] == 0.f) continue;                  // padding point
+            float key[RB];
+            unsigned biased[RB], e[RB];
+            // phase 1: residuals of rotation pairs (packed FP32), fixed point, table read
+            const f32x2 xx = {x4[u], x4[u]}, yy = {y4[u], y4[u]}, zz = {z4[u], z4[u]};
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                float v = __builtin_fmaf(w[rb][0], x4[u], __builtin_fmaf(w[rb][1], y4[u], w[rb][2] * z4[u])) + w[rb][3];
-                v = __builtin_amdgcn_fmed3f(v, -64.f, 64.f);   // the sums hold 64 m per point; a NaN turns finite
-                const float key = -v;
-                // k = #{q : sbs[q] < key}.  The bucket function is monotone and the table was built
-                // with this very expression: every threshold of a lower bucket is below the key, every
-                // threshold of a higher bucket above it, so k is the table entry (thresholds in lower
-                // buckets) plus the thresholds of the key's own bucket that lie below it.  Most buckets
-                // hold none (no further read) or one (one comparison).
-                const int bucket = separable_bucket(key, mt, M);
-                const unsigned e = tabs[bucket];
-                int k = (int)(e & kSepRankMask);
-                if (e > kSepRankMask) {
-                    const bool below = sbs[k] < key;
-                    k += below ? 1 : 0;
-                    if (below && (e >> kSepRankBits) > 1u) {   // a crowded bucket: search the rest of it
-                        int hi = (int)(tabs[bucket + 1] & kSepRankMask);
-                        while (k < hi) {
-                            const int mid = (k + hi) >> 1;
-                            if (sbs[mid] < key) k = mid + 1; else hi = mid;
-                        }
-                    }
-                }
-                const double dv = (double)v + 1572864.0;   // 1.5 * 2^20: low bits = v * 2^32, rounded
-                const unsigned long long fx = (unsigned long long)__double_as_longlong(dv);
-                // the two outer bins take every point beyond the thresholds (most points, for
-                // rotations far from the optimum): those are kept in registers
-                if (k == 0) { ++c_lo[rb]; s_lo[rb] += fx; }
-                else if (k == nt) { ++c_hi[rb]; s_hi[rb] += fx; }
-                else {
-                    atomicAdd(&cnt[rb][k], 1u);
-                    atomicAdd(&sum[rb][k], fx);
+            for (int rp = 0; rp < RB / 2; ++rp) {
+                const f32x2 v2 = __builtin_elementwise_fma(w0[rp], xx, __builtin_elementwise_fma(w1[rp], yy, w2[rp] * zz)) + w3[rp];
+                const f32x2 f2 = v2 * fx2;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int rb = 2 * rp + h;
+                    key[rb] = -v2[h];
+                    biased[rb] = (unsigned)(int)f2[h] ^ 0x80000000u;         // towards zero: below one unit
+                    // k = #{q : sbs[q] < key}.  The bucket function is monotone and the table was built with
+                    // this very expression: every threshold of a lower bucket is below the key, every threshold
+                    // of a higher bucket above it, so k is the table entry (thresholds in lower buckets) plus
+                    // the thresholds of the key's own bucket that lie below it.
+                    e[rb] = tabs[separable_bucket(key[rb], mt, M)];
                 }
             }
+            // phase 2: the first threshold that could still lie below the key
+            float thr[RB];
+            unsigned k[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                k[rb] = e[rb] & kSepRankMask;
+                thr[rb] = sbs[k[rb]];
+            }
+            unsigned crowded = 0u;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const unsigned below = thr[rb] < key[rb] ? 1u : 0u;
+                k[rb] += below;
+                crowded |= below ? e[rb] : 0u;                               // bit 13: two thresholds or more
+            }
+            // phase 3 (rare): a bucket with several thresholds, the first of them below the key
+            if (__builtin_amdgcn_ballot_w64((crowded >> (kSepRankBits + 1)) != 0u) != 0ull) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    if (!(thr[rb] < key[rb] && (e[rb] >> (kSepRankBits + 1)) != 0u)) continue;
+                    unsigned hi = tabs[separable_bucket(key[rb], mt, M) + 1] & kSepRankMask;
+                    unsigned kk = k[rb];
+                    while (kk < hi) {
+                        const unsigned mid = (kk + hi) >> 1;
+                        if (sbs[mid] < key[rb]) kk = mid + 1; else hi = mid;
+                    }
+                    k[rb] = kk;
+                }
+            }
+            // phase 4: outer bins in registers, the others in the histogram
+            const bool valid = !kCheck || o4[u] != 0.f;                      // not a padding point
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const bool lo = valid && k[rb] == 0u, hi = k[rb] == (unsigned)nt;
+                c_lo[rb] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lo));
+                s_all[rb] += valid ? biased[rb] : 0u;
+                s_lo[rb] += lo ? biased[rb] : 0u;
+                if (valid && !lo && !hi) atomicAdd(&pk[rb][k[rb]], (1ull << 48) + (unsigned long long)biased[rb]);
+            }
+        }
+    };
+
+    // points: a wave takes four 64-point groups per trip, a lane the four points of one column; padding
+    // points exist in a cloud's last group only
+    const int g0 = group_off[j], g1 = group_off[j + 1];
+    const int64_t n_points = cloud_pt_off[j + 1] - cloud_pt_off[j];
+    const int col = lane & 15, gsel = lane >> 4;
+    int trips = 0;
+    for (int gb = g0; gb < g1; gb += kWaves * 4) {
+        const int g = gb + wave * 4 + gsel;
+        if (g < g1) {
+            const f32x4* gp = groups + (int64_t)g * 64 + col;
+            if (__builtin_amdgcn_ballot_w64(g == g1 - 1) != 0ull) trip(gp, std::true_type{});
+            else trip(gp, std::false_type{});
+        }
+        if (++trips == kSepFlushTrips) {          // uniform over the workgroup
+            trips = 0;
+            __syncthreads();
+            flush();
+            __syncthreads();
         }
     }
+    __syncthreads();
+    flush();
+    __syncthreads();
+    // the outer bins: the count below the first threshold is already a wave total; the sums are reduced
+    // over the wave, and one lane per wave adds (c_lo, s_lo) to bin 0 and s_all to the rotation's total
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        if (c_lo[rb]) { atomicAdd(&cnt[rb][0], c_lo[rb]); atomicAdd(&sum[rb][0], s_lo[rb]); }
-        if (c_hi[rb]) { atomicAdd(&cnt[rb][nt], c_hi[rb]); atomicAdd(&sum[rb][nt], s_hi[rb]); }
+        long long sl = (long long)s_lo[rb], sa = (long long)s_all[rb];
+        for (int off = 32; off > 0; off >>= 1) {
+            sl += __shfl_xor(sl, off, 64);
+            sa += __shfl_xor(sa, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&wcnt[rb * (TC + 1)], c_lo[rb]);
+            atomicAdd((unsigned long long*)&wsum[rb * (TC + 1)], (unsigned long long)(sl - ((long long)c_lo[rb] << 31)));
+            atomicAdd((unsigned long long*)&tot_all_s[rb], (unsigned long long)sa);
+        }
     }
+    __threadfence_block();
     __syncthreads();
 
-    // inclusive prefix sums over the bins, one wave per rotation
+    // inclusive prefix sums over the bins in place, one wave per rotation; the totals go to LDS
     for (int rb = wave; rb < RB; rb += kWaves) {
         unsigned long long cn = 0;
         long long cs = 0;
         for (int base = 0; base <= nt; base += 64) {
-            const int k = base + lane;
+            const int kk = base + lane;
             unsigned long long c = 0;
             long long sv = 0;
-            if (k <= nt) {
-                c = cnt[rb][k];
-                sv = (long long)(sum[rb][k] - c * kMagicBits);
+            if (kk <= nt) {
+                c = wcnt[rb * (TC + 1) + kk];
+                sv = wsum[rb * (TC + 1) + kk];
             }
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -1104,26 +1216,35 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
             }
             c += cn;
             sv += cs;
-            if (k <= nt) {
-                cnt[rb][k] = (unsigned int)c;
-                sum[rb][k] = (unsigned long long)sv;
+            if (kk <= nt) {
+                wcnt[rb * (TC + 1) + kk] = (unsigned int)c;
+                wsum[rb * (TC + 1) + kk] = sv;
             }
             cn = __shfl(c, 63, 64);
             cs = __shfl(sv, 63, 64);
         }
+        // the top bin is never stored: the count of all points is the cloud's size, and the sum of
+        // everything is s_all less the bias of all points
+        if (lane == 0) {
+            const unsigned long long n_all = (unsigned long long)n_points;
+            tot_c[rb] = n_all;
+            tot_s[rb] = tot_all_s[rb] - (long long)(n_all << 31);
+        }
     }
+    __threadfence_block();
     __syncthreads();
 
     const double sc = scale[j];
+    const double inv_fx = 1.0 / (double)fx_scale;
     for (int q = threadIdx.x; q < nt; q += kSepThreads) {
         const double bq = (double)sbs[q];
         const int tl = perm[(int64_t)j * nt + q];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if (r0 + rb >= nr) break;
-            const double n_le = (double)cnt[rb][q], n_all = (double)cnt[rb][nt];
-            const double s_le = (double)(long long)sum[rb][q], s_all = (double)(long long)sum[rb][nt];
-            const double f = (2.0 * s_le - s_all) * (1.0 / 4294967296.0) + bq * (2.0 * n_le - n_all);
+            const double n_le = (double)wcnt[rb * (TC + 1) + q], n_all = (double)tot_c[rb];
+            const double s_le = (double)wsum[rb * (TC + 1) + q], s_all = (double)tot_s[rb];
+            const double f = (2.0 * s_le - s_all) * inv_fx + bq * (2.0 * n_le - n_all);
             partial[((int64_t)j * nt + tl) * nr + (r0 + rb)] = f * sc;
         }
     }
