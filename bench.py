@@ -251,6 +251,9 @@ def main():
             "search": args.search,
             "parallelism": f"candidate shards x{world}, RCCL all-gather argmin" if world > 1 else "single GPU",
         },
+        "value_note": None if args.search == "dense" else
+                      "separable search: candidates x points per second as if every residual were evaluated; none is "
+                      "(one histogram pass per rotation answers all its translations) -- not the metric, no roofline",
         "best_index": idx,
         "best_cost": cost,
         "n_rescored": int(st.n_rescored),

@@ -1167,9 +1167,17 @@ extern "C" int ccal_argmin_merge(int n, const double* costs, const int64_t* indi
 // ---------------------------------------------------------------------------
 // separable search: all translations of a rotation from one pass over the points
 // ---------------------------------------------------------------------------
-// Translations per launch (histogram bins in LDS, 8 bytes each) x rotations per workgroup: 1024 x 4
-// when one launch holds all translations (53 KB of LDS: three workgroups per CU); 2048 x 2 for longer
-// lists, which halves the number of launches (57 KB).
+// Translations per launch (histogram bins in LDS, 8 bytes each) x rotations per workgroup.  Every launch
+// evaluates every (rotation, point) pair anew, so the work of a search is pairs x launches and the widest
+// form that fits is the fastest for a long list even though it leaves one workgroup per CU.
+struct SepForm { int tc, rb, bpb; };
+static SepForm separable_form(int64_t n_translations)
+{
+    if (n_translations <= 1024) return {1024, 4, 8};    //  53 KB of LDS: three workgroups of 512 threads per CU
+    if (n_translations <= 2048) return {2048, 2, 4};    //  57 KB: two
+    return {5120, 2, 4};                                // 143 KB: one workgroup of 1024 threads
+}
+
 // Scale of the separable pass's fixed point for residuals bounded by vmax: the largest power of two with
 // vmax * scale < 2^31 (capped at 2^40; 1 for a non-finite bound, which the pass is never run with).
 static double separable_fx_scale(double vmax)
@@ -1180,9 +1188,7 @@ static double separable_fx_scale(double vmax)
     return std::ldexp(1.0, e);
 }
 
-constexpr int kSepBucketsShort = 8, kSepBucketsLong = 4;   // lookup-table buckets per bin (LDS: 16 KB either way)
-
-template <int TC, int RB, int BPB>
+template <int TC, int RB, int BPB, int NT>
 static hipError_t launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x4* wr, int nt, int nr, float fx_scale)
 {
     // wide accumulators: one slice of RB x (TC + 1) bins per workgroup
@@ -1190,8 +1196,8 @@ static hipError_t launch_separable(ccal_ctx* ctx, const CloudSet& cs, const f32x
     hipError_t e = ctx->sep_wcnt.ensure(n_wg * bins * sizeof(unsigned int));
     if (e == hipSuccess) e = ctx->sep_wsum.ensure(n_wg * bins * sizeof(long long));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((separable_hist_kernel<TC, RB, BPB>), dim3((nr + RB - 1) / RB, cs.n_clouds),
-                       dim3(kSepThreads), 0, ctx->stream, cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+    hipLaunchKernelGGL((separable_hist_kernel<TC, RB, BPB, NT>), dim3((nr + RB - 1) / RB, cs.n_clouds),
+                       dim3(NT), 0, ctx->stream, cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
                        wr, ctx->sep_sb.as<float>(), ctx->sep_perm.as<int>(), ctx->sep_tab.as<unsigned short>(),
                        ctx->sep_meta.as<SepMeta>(), cs.scale_dev.as<double>(), cs.cloud_pt_off_dev.as<int64_t>(),
                        cs.n_clouds, nt, nr, fx_scale, ctx->sep_wcnt.as<unsigned int>(), ctx->sep_wsum.as<long long>(), ctx->partial_buf.as<double>());
@@ -1225,11 +1231,12 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
     auto b_of = [&](int j, const double tf[3]) {
         return (gj[3 * j] * tf[0] + gj[3 * j + 1] * tf[1] + gj[3 * j + 2] * tf[2] + hj[j]) * fc.inv_norm;
     };
-    // reference constant per cloud: the middle translation of the whole range
+    // reference constant per cloud: the middle translation of the whole grid (not of [t0, t1): the costs
+    // of a translation are then the same bits whichever range of the grid a call covers)
     std::vector<double> bref(C);
     {
         double tf[3];
-        translation((t0 + t1) / 2, tf);
+        translation((int64_t)g->count[0] * g->count[1] * g->count[2] / 2, tf);
         for (int j = 0; j < C; ++j) bref[j] = b_of(j, tf);
     }
 
@@ -1270,9 +1277,8 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 
     // fixed point of the histogram sums: the power of two that keeps |u| * fx_scale below 2^31
     const float fx_scale = (float)separable_fx_scale(vmax);
-    const bool long_list = t1 - t0 > 1024;
-    const int tc = long_list ? 2048 : 1024, rb = long_list ? 2 : 4;
-    const int bpb = long_list ? kSepBucketsLong : kSepBucketsShort;
+    const SepForm form = separable_form(t1 - t0);
+    const int tc = form.tc, rb = form.rb, bpb = form.bpb;
     const int M = bpb * tc;
     std::vector<float> sb;
     std::vector<int> perm;
@@ -1333,8 +1339,9 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)C * nt * nr * sizeof(double)));
             CCAL_HIP(ctx, hipEventRecord(e0, ctx->stream));
             const f32x4* wr_dev = ctx->sep_wr.as<f32x4>() + (size_t)ra * C;
-            if (long_list) CCAL_HIP(ctx, (launch_separable<2048, 2, kSepBucketsLong>(ctx, cs, wr_dev, nt, nr, fx_scale)));
-            else CCAL_HIP(ctx, (launch_separable<1024, 4, kSepBucketsShort>(ctx, cs, wr_dev, nt, nr, fx_scale)));
+            if (tc == 1024) CCAL_HIP(ctx, (launch_separable<1024, 4, 8, 512>(ctx, cs, wr_dev, nt, nr, fx_scale)));
+            else if (tc == 2048) CCAL_HIP(ctx, (launch_separable<2048, 2, 4, 512>(ctx, cs, wr_dev, nt, nr, fx_scale)));
+            else CCAL_HIP(ctx, (launch_separable<5120, 2, 4, 1024>(ctx, cs, wr_dev, nt, nr, fx_scale)));
             CCAL_HIP(ctx, hipEventRecord(e1, ctx->stream));
             hipLaunchKernelGGL(separable_reduce_kernel, dim3((unsigned)(((int64_t)nt * nr + 255) / 256)), dim3(256),
                                0, ctx->stream, ctx->partial_buf.as<double>(), C, nt, nr, cost, R, ta - t0, ra);

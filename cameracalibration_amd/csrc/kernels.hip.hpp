@@ -965,7 +965,6 @@ __global__ __launch_bounds__(256) void select_band_kernel(const float* __restric
 // not depend on the order of the atomics.
 //
 // One workgroup = RB rotations x one cloud x one range of at most TC translations.
-constexpr int kSepThreads = 512;
 
 struct SepMeta {
     float inv_delta;   // buckets per metre
@@ -987,9 +986,9 @@ __host__ __device__ inline int separable_bucket(float key, const SepMeta& mt, in
     return (int)fb;
 }
 
-// Lookup-table entry: rank of the bucket's first threshold in the low 12 bits (at most 2048
+// Lookup-table entry: rank of the bucket's first threshold in the low 13 bits (at most 8191
 // thresholds per launch), thresholds in the bucket (0, 1, 2 = two or more) above them.
-constexpr unsigned kSepRankBits = 12, kSepRankMask = (1u << kSepRankBits) - 1u;
+constexpr unsigned kSepRankBits = 13, kSepRankMask = (1u << kSepRankBits) - 1u;
 
 // BPB = buckets of the lookup table per histogram bin: with several the typical bucket holds no
 // threshold or one, so the rank of a key is the table entry plus one or two comparisons.
@@ -1001,8 +1000,8 @@ constexpr unsigned kSepRankBits = 12, kSepRankMask = (1u << kSepRankBits) - 1u;
 //
 // A bin is ONE 64-bit word in LDS: count in the top 16 bits, the sum of the biased values (fixed point
 // + 2^31, below 2^32) in the low 48, so a point costs one LDS atomic.  The word holds 65535 points
-// without a carry into the count; every kSepFlushTrips trips of the point loop (2048 points per trip)
-// the workgroup empties its words into wide (32-bit count, 64-bit sum) accumulators in global memory
+// without a carry into the count; before a workgroup has put that many points into its words (every 31
+// trips of the point loop at 2048 points per trip) it empties its words into wide (32-bit count, 64-bit sum) accumulators in global memory
 // -- its own slice, touched a handful of times per cloud, L2-resident.  With 8 bytes of LDS per bin a
 // workgroup can serve RB = 4 rotations from one pass over the cloud's points (the pass is bound by the
 // rate at which the points come out of L2: 16 bytes per point and workgroup).
@@ -1010,10 +1009,11 @@ constexpr unsigned kSepRankBits = 12, kSepRankMask = (1u << kSepRankBits) - 1u;
 // The point loop works on all 4 points x RB rotations of a trip at once, phase by phase (values and
 // table reads; threshold reads; the rare crowded buckets; atomics), so that the LDS reads of a trip
 // are in flight together instead of one round trip per item.
-constexpr int kSepFlushTrips = 31;   // 31 * 2048 = 63488 points < 65536
-
-template <int TC, int RB, int BPB>
-__global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
+//
+// NT = threads per workgroup: 512 where two or three workgroups share a CU, 1024 for the widest form,
+// whose tables fill most of a CU's LDS.
+template <int TC, int RB, int BPB, int NT>
+__global__ __launch_bounds__(NT) void separable_hist_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off,
     const f32x4* __restrict__ wr,            // [rotation][cloud]: w1, w2, w3, a
     const float* __restrict__ sb,            // [cloud][nt]: sorted translation constants
@@ -1036,16 +1036,18 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
     const int j = blockIdx.y;
     const int r0 = blockIdx.x * RB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int kWaves = kSepThreads / 64;
+    constexpr int kWaves = NT / 64;
+    constexpr int kSepFlushTrips = 65535 / (kWaves * 256);   // a trip = 256 points per wave
+    static_assert(TC < (1 << kSepRankBits), "ranks must fit the lookup-table entry");
     const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     unsigned int* wcnt = wide_cnt + wg * kBins;
     long long* wsum = wide_sum + wg * kBins;
 
-    for (int i = threadIdx.x; i <= nt; i += kSepThreads) sbs[i] = i < nt ? sb[(int64_t)j * nt + i] : __builtin_inff();
-    for (int i = threadIdx.x; i <= M; i += kSepThreads) tabs[i] = tab[(int64_t)j * (M + 1) + i];
-    for (int i = threadIdx.x; i < kBins; i += kSepThreads) {
+    for (int i = threadIdx.x; i <= nt; i += NT) sbs[i] = i < nt ? sb[(int64_t)j * nt + i] : __builtin_inff();
+    for (int i = threadIdx.x; i <= M; i += NT) tabs[i] = tab[(int64_t)j * (M + 1) + i];
+    for (int i = threadIdx.x; i < kBins; i += NT) {
         (&pk[0][0])[i] = 0ull;
-        wcnt[i] = 0u;          // thread t owns bins t, t + kSepThreads, ... in every pass over them
+        wcnt[i] = 0u;          // thread t owns bins t, t + NT, ... in every pass over them
         wsum[i] = 0ll;
     }
     if (threadIdx.x < RB) tot_all_s[threadIdx.x] = 0ll;
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
 
     auto flush = [&]() {
         // every bin by the thread that owns it: plain read-modify-write, no atomics
-        for (int i = threadIdx.x; i < kBins; i += kSepThreads) {
+        for (int i = threadIdx.x; i < kBins; i += NT) {
             const unsigned long long p = (&pk[0][0])[i];
             if (p == 0ull) continue;
             const unsigned long long c = p >> 48;
@@ -1236,7 +1238,7 @@ __global__ __launch_bounds__(kSepThreads) void separable_hist_kernel(
 
     const double sc = scale[j];
     const double inv_fx = 1.0 / (double)fx_scale;
-    for (int q = threadIdx.x; q < nt; q += kSepThreads) {
+    for (int q = threadIdx.x; q < nt; q += NT) {
         const double bq = (double)sbs[q];
         const int tl = perm[(int64_t)j * nt + q];
 #pragma unroll

@@ -292,7 +292,8 @@ def test_separable_search_equals_dense(gpu_opt, oracle):
     upload(gpu_opt, s)
     o = oracle.OracleScene(s.clouds, s.base_T_flange)
     try:
-        for counts in ([3, 4, 5, 4, 3, 5], [11, 11, 11, 2, 2, 2]):       # 60 and 1331 translations
+        # 60, 1331, 2744 and 5508 translations: the three widths of the pass, the widest in one launch and in two
+        for counts in ([3, 4, 5, 4, 3, 5], [11, 11, 11, 2, 2, 2], [14, 14, 14, 2, 1, 3], [18, 18, 17, 1, 2, 1]):
             g = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / max(c - 1, 1) for c in counts[:3]] +
                              [10.0 / max(c - 1, 1) for c in counts[3:]], counts)
             rot = counts[3] * counts[4] * counts[5]
@@ -562,8 +563,8 @@ def test_grid_search_more_near_ties_than_one_list(gpu_opt, oracle, ccal, mode):
 
 
 def test_separable_search_leaves_far_scenes_to_the_dense_sweep(gpu_opt, oracle, ccal):
-    """Signed distances beyond the 64 m the histogram pass keeps in fixed point (a scene in millimetre-like
-    units): the separable mode must not saturate silently; it answers with the oracle's winner."""
+    """Signed distances of hundreds of units (a scene in millimetre-like units): the fixed point of the
+    histogram pass scales with the scene instead of saturating; the answer is the oracle's winner."""
     rng = np.random.default_rng(6)
     clouds = [(rng.normal(0, 40.0, (n, 3)) * [1, 1, 0.05] + [0, 0, 300.0]).astype(np.float32) for n in (500, 800)]
     B = np.stack([ccal.pose_to_matrix([5.0, -3.0, 2.0, 0.1, -0.2, 0.05]).reshape(16),
