@@ -1310,16 +1310,16 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             const double delta = range > 1e-30 ? range / M : 1.0;
             meta[j].inv_delta = (float)(1.0 / delta);
             meta[j].offset = (float)(-(double)bmin / delta);
-            // entry m: thresholds in buckets below m (the rank a key of bucket m starts from) and how
-            // many bucket m holds itself (0, 1, 2 = more); [M] = nt
+            // entry m: four times the number of thresholds in buckets below m (the rank a key of bucket m
+            // starts from), flagged when bucket m holds two or more itself; [M] = 4 nt
             unsigned short* tj = tab.data() + (size_t)j * (M + 1);
             int q = 0;
             for (int m = 0; m < M; ++m) {
                 const int lo = q;
                 while (q < nt && separable_bucket(order[q].first, meta[j], M) <= m) ++q;
-                tj[m] = (unsigned short)((unsigned)lo | ((unsigned)std::min(q - lo, 2) << kSepRankBits));
+                tj[m] = (unsigned short)(4u * (unsigned)lo | (q - lo >= 2 ? kSepCrowded : 0u));
             }
-            tj[M] = (unsigned short)nt;
+            tj[M] = (unsigned short)(4 * nt);
         }
         // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
         const int64_t budget = (int64_t)1 << 30;
@@ -1376,7 +1376,7 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 //   accumulation:   128 FP32 adds per lane partial + 4 in the promotion, of non-negative terms:
 //                relative 132u of the sum; one more u for the float the cost is stored as.
 //   separable pass: w, p - c, the rotation constant a and the translation constant b rounded to float,
-//                a four-rounding FP32 chain on magnitudes <= rn |p - c| + |a|, 2^-32 m fixed point
+//                an FP32 chain of three fused steps (budgeted as four roundings) on magnitudes <= rn |p - c| + |a|, fixed point
 //                (truncation: below one unit; the sign taken from the unrounded value: one more; budgeted as three):
 //                u (6 rn rho + 5 A + B) + 3 units
 //                of the fixed point (a unit = 2^-30 of the largest possible |residual|, rounded up to

@@ -959,10 +959,10 @@ __global__ __launch_bounds__(256) void select_band_kernel(const float* __restric
 // k_i = #{t : b_t < -u_i}; per bin a count and the sum of u; then with prefix
 // sums N(q), S(q) over bins <= q
 //   f(b_q) = 2 S(q) - S_total + b_q (2 N(q) - N).
-// Work per (rotation, point) is a short search and two LDS atomics instead of
-// one residual per translation.  Sums are integers (u rounded to 2^-32 m by the
-// magic-number add, accumulated with 64-bit integer atomics), so the result does
-// not depend on the order of the atomics.
+// Work per (rotation, point) is two LDS reads and one LDS atomic instead of one
+// residual per translation.  Sums are integers (u in 32-bit fixed point,
+// accumulated with 64-bit integer atomics), so the result does not depend on the
+// order of the atomics.
 //
 // One workgroup = RB rotations x one cloud x one range of at most TC translations.
 
@@ -986,9 +986,10 @@ __host__ __device__ inline int separable_bucket(float key, const SepMeta& mt, in
     return (int)fb;
 }
 
-// Lookup-table entry: rank of the bucket's first threshold in the low 13 bits (at most 8191
-// thresholds per launch), thresholds in the bucket (0, 1, 2 = two or more) above them.
-constexpr unsigned kSepRankBits = 13, kSepRankMask = (1u << kSepRankBits) - 1u;
+// Lookup-table entry (16 bits): four times the rank of the bucket's first threshold -- the byte offset
+// of that threshold in the sorted list, and half the byte offset of its histogram word -- with the top
+// bit set when the bucket holds two thresholds or more.  At most 8191 thresholds per launch.
+constexpr unsigned kSepCrowded = 0x8000u, kSepOffsetMask = 0x7ffcu;
 
 // BPB = buckets of the lookup table per histogram bin: with several the typical bucket holds no
 // threshold or one, so the rank of a key is the table entry plus one or two comparisons.
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
     const f32x4* __restrict__ wr,            // [rotation][cloud]: w1, w2, w3, a
     const float* __restrict__ sb,            // [cloud][nt]: sorted translation constants
     const int* __restrict__ perm,            // [cloud][nt]: rank -> local translation index
-    const unsigned short* __restrict__ tab,  // [cloud][M + 1]: see kSepRankBits; entry [M] = nt
+    const unsigned short* __restrict__ tab,  // [cloud][M + 1]: see kSepCrowded; entry [M] = 4 nt
     const SepMeta* __restrict__ meta,        // [cloud]
     const double* __restrict__ scale,        // [cloud]: 1 / (n_clouds * n_points)
     const int64_t* __restrict__ cloud_pt_off,
@@ -1038,12 +1039,14 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kWaves = NT / 64;
     constexpr int kSepFlushTrips = 65535 / (kWaves * 256);   // a trip = 256 points per wave
-    static_assert(TC < (1 << kSepRankBits), "ranks must fit the lookup-table entry");
+    static_assert(4 * TC <= (int)kSepOffsetMask, "ranks must fit the lookup-table entry");
     const int64_t wg = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     unsigned int* wcnt = wide_cnt + wg * kBins;
     long long* wsum = wide_sum + wg * kBins;
 
-    for (int i = threadIdx.x; i <= nt; i += NT) sbs[i] = i < nt ? sb[(int64_t)j * nt + i] : __builtin_inff();
+    // thresholds, rotation vectors and the bucket function in units of the fixed point (fx_scale is a power
+    // of two: the scaled values are the same numbers, and a residual converts to its integer as it is)
+    for (int i = threadIdx.x; i <= nt; i += NT) sbs[i] = i < nt ? sb[(int64_t)j * nt + i] * fx_scale : __builtin_inff();
     for (int i = threadIdx.x; i <= M; i += NT) tabs[i] = tab[(int64_t)j * (M + 1) + i];
     for (int i = threadIdx.x; i < kBins; i += NT) {
         (&pk[0][0])[i] = 0ull;
@@ -1058,17 +1061,18 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
     for (int rp = 0; rp < RB / 2; ++rp) {
         const int ra = r0 + 2 * rp < nr ? r0 + 2 * rp : nr - 1;       // a partial last group repeats its last rotation
         const int rc = r0 + 2 * rp + 1 < nr ? r0 + 2 * rp + 1 : nr - 1;
-        const f32x4 a = wr[(int64_t)ra * n_clouds + j], c = wr[(int64_t)rc * n_clouds + j];
+        const f32x4 a = wr[(int64_t)ra * n_clouds + j] * fx_scale, c = wr[(int64_t)rc * n_clouds + j] * fx_scale;
         w0[rp] = f32x2{a[0], c[0]}; w1[rp] = f32x2{a[1], c[1]}; w2[rp] = f32x2{a[2], c[2]}; w3[rp] = f32x2{a[3], c[3]};
     }
-    const f32x2 fx2 = {fx_scale, fx_scale};
-    const SepMeta mt = meta[j];
+    SepMeta mt = meta[j];
+    mt.inv_delta /= fx_scale;
     // The two outer bins (every point beyond the thresholds: most points, for rotations far from the
     // optimum) never touch LDS.  Their counts are wave-wide population counts (scalar registers); of the
     // sums a lane keeps the one of ALL its points and the one of the points below the first threshold --
     // the sum above the last threshold is what is left once the bins in between are known.
     unsigned c_lo[RB] = {};
     unsigned long long s_all[RB] = {}, s_lo[RB] = {};
+    const unsigned top8 = 8u * (unsigned)nt;
     __syncthreads();
 
     auto flush = [&]() {
@@ -1084,10 +1088,11 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
     };
 
     // One trip of a lane: the four points of its column of group g, all RB rotations, one point (RB items)
-    // at a time and phase by phase, written without branches: flags are integers, every item reads the
-    // table and its bucket's first threshold (an empty bucket's entry is the rank of the NEXT threshold,
-    // which lies in a higher bucket and so above the key: the comparison adds nothing; one past the last
-    // threshold sits +infinity).  kCheck: the group may hold padding points.
+    // at a time and phase by phase.  Every item reads the table and its bucket's first threshold (an empty
+    // bucket's entry names the NEXT threshold, which lies in a higher bucket and so above the key: the
+    // comparison adds nothing; one past the last threshold sits +infinity).  All offsets stay in bytes: the
+    // table entry is the offset of the threshold, twice that the offset of the histogram word.
+    // kCheck: the group may hold padding points.
     auto trip = [&](const f32x4* gp, auto check) {
         constexpr bool kCheck = decltype(check)::value;
         const f32x4 x4 = gp[0], y4 = gp[16], z4 = gp[32];
@@ -1095,64 +1100,62 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
         if (kCheck) o4 = gp[48];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float key[RB];
-            unsigned biased[RB], e[RB];
-            // phase 1: residuals of rotation pairs (packed FP32), fixed point, table read
+            float v[RB], thr[RB];
+            unsigned e[RB];
+            // phase 1: residuals of rotation pairs (packed FP32, three roundings), table read
             const f32x2 xx = {x4[u], x4[u]}, yy = {y4[u], y4[u]}, zz = {z4[u], z4[u]};
 #pragma unroll
             for (int rp = 0; rp < RB / 2; ++rp) {
-                const f32x2 v2 = __builtin_elementwise_fma(w0[rp], xx, __builtin_elementwise_fma(w1[rp], yy, w2[rp] * zz)) + w3[rp];
-                const f32x2 f2 = v2 * fx2;
+                const f32x2 v2 = __builtin_elementwise_fma(w0[rp], xx, __builtin_elementwise_fma(w1[rp], yy,
+                                 __builtin_elementwise_fma(w2[rp], zz, w3[rp])));
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int rb = 2 * rp + h;
-                    key[rb] = -v2[h];
-                    biased[rb] = (unsigned)(int)f2[h] ^ 0x80000000u;         // towards zero: below one unit
-                    // k = #{q : sbs[q] < key}.  The bucket function is monotone and the table was built with
+                    v[rb] = v2[h];
+                    // k = #{q : sbs[q] < -v}.  The bucket function is monotone and the table was built with
                     // this very expression: every threshold of a lower bucket is below the key, every threshold
                     // of a higher bucket above it, so k is the table entry (thresholds in lower buckets) plus
                     // the thresholds of the key's own bucket that lie below it.
-                    e[rb] = tabs[separable_bucket(key[rb], mt, M)];
+                    e[rb] = tabs[separable_bucket(-v[rb], mt, M)];
                 }
             }
             // phase 2: the first threshold that could still lie below the key
-            float thr[RB];
-            unsigned k[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                thr[rb] = *(const float*)((const char*)sbs + (e[rb] & kSepOffsetMask));
+            unsigned k8[RB];
+            unsigned long long crowded = 0ull;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                k[rb] = e[rb] & kSepRankMask;
-                thr[rb] = sbs[k[rb]];
-            }
-            unsigned crowded = 0u;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const unsigned below = thr[rb] < key[rb] ? 1u : 0u;
-                k[rb] += below;
-                crowded |= below ? e[rb] : 0u;                               // bit 13: two thresholds or more
+                const bool below = thr[rb] < -v[rb];
+                k8[rb] = 2u * (e[rb] & kSepOffsetMask) + (below ? 8u : 0u);
+                crowded |= __builtin_amdgcn_ballot_w64(below) & __builtin_amdgcn_ballot_w64(e[rb] >= kSepCrowded);
             }
             // phase 3 (rare): a bucket with several thresholds, the first of them below the key
-            if (__builtin_amdgcn_ballot_w64((crowded >> (kSepRankBits + 1)) != 0u) != 0ull) {
+            if (crowded != 0ull) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    if (!(thr[rb] < key[rb] && (e[rb] >> (kSepRankBits + 1)) != 0u)) continue;
-                    unsigned hi = tabs[separable_bucket(key[rb], mt, M) + 1] & kSepRankMask;
-                    unsigned kk = k[rb];
+                    if (!(thr[rb] < -v[rb] && e[rb] >= kSepCrowded)) continue;
+                    unsigned hi = (tabs[separable_bucket(-v[rb], mt, M) + 1] & kSepOffsetMask) >> 2;
+                    unsigned kk = k8[rb] >> 3;
                     while (kk < hi) {
                         const unsigned mid = (kk + hi) >> 1;
-                        if (sbs[mid] < key[rb]) kk = mid + 1; else hi = mid;
+                        if (sbs[mid] < -v[rb]) kk = mid + 1; else hi = mid;
                     }
-                    k[rb] = kk;
+                    k8[rb] = kk << 3;
                 }
             }
             // phase 4: outer bins in registers, the others in the histogram
             const bool valid = !kCheck || o4[u] != 0.f;                      // not a padding point
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const bool lo = valid && k[rb] == 0u, hi = k[rb] == (unsigned)nt;
+                const unsigned biased = (unsigned)(int)v[rb] ^ 0x80000000u;   // towards zero: below one unit
+                const bool lo = valid && k8[rb] == 0u, hi = k8[rb] == top8;
                 c_lo[rb] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lo));
-                s_all[rb] += valid ? biased[rb] : 0u;
-                s_lo[rb] += lo ? biased[rb] : 0u;
-                if (valid && !lo && !hi) atomicAdd(&pk[rb][k[rb]], (1ull << 48) + (unsigned long long)biased[rb]);
+                s_all[rb] += valid ? biased : 0u;
+                if (lo) s_lo[rb] += biased;
+                if (valid && !lo && !hi)
+                    atomicAdd((unsigned long long*)((char*)&pk[rb][0] + k8[rb]), (1ull << 48) + (unsigned long long)biased);
             }
         }
     };
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(NT) void separable_hist_kernel(
     const double sc = scale[j];
     const double inv_fx = 1.0 / (double)fx_scale;
     for (int q = threadIdx.x; q < nt; q += NT) {
-        const double bq = (double)sbs[q];
+        const double bq = (double)sbs[q] * inv_fx;
         const int tl = perm[(int64_t)j * nt + q];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {

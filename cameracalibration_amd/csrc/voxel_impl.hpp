@@ -133,6 +133,66 @@ __global__ __launch_bounds__(64) void voxel_centroid_kernel(
     out[3 * (size_t)v + 2] = sz / cnt;
 }
 
+// The same sums for long runs: one wave per run.  The wave reads the run 512 elements at a time with
+// coalesced loads (the next piece is in flight while the present one is added) and hands it through LDS
+// to three of its lanes, one per coordinate, which add their elements one at a time in order.
+constexpr int kCentroidPiece = 512;     // elements per piece and coordinate (8 per lane)
+constexpr int kCentroidWaves = 4;       // waves per workgroup (each works on runs of its own)
+
+__global__ __launch_bounds__(64 * kCentroidWaves) void voxel_centroid_wave_kernel(
+    const float* __restrict__ gx, const float* __restrict__ gy, const float* __restrict__ gz,
+    const unsigned int* __restrict__ counts, const unsigned int* __restrict__ offsets, unsigned int n_runs,
+    float* __restrict__ out /* AoS xyz */)
+{
+    __shared__ __attribute__((aligned(16))) float buf[kCentroidWaves][3][kCentroidPiece];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int n_waves = gridDim.x * kCentroidWaves;
+    constexpr int kPerLane = kCentroidPiece / 64;
+    const float* g[3] = {gx, gy, gz};
+    for (unsigned int v = blockIdx.x * kCentroidWaves + wave; v < n_runs; v += n_waves) {
+        const size_t o = offsets[v];
+        const unsigned int c = counts[v];
+        float s = 0.f;                               // lane k < 3: the sum of coordinate k
+        float r[3][kPerLane];
+        auto fetch = [&](unsigned int t0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < kPerLane; ++u) {
+                    const unsigned int i = t0 + (unsigned)(u * 64 + lane);
+                    r[k][u] = i < c ? g[k][o + i] : 0.f;
+                }
+        };
+        fetch(0);
+        for (unsigned int t0 = 0; t0 < c; t0 += kCentroidPiece) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < kPerLane; ++u) buf[wave][k][u * 64 + lane] = r[k][u];
+            if (t0 + kCentroidPiece < c) fetch(t0 + kCentroidPiece);
+            // LDS operations of one wave complete in order; the fences keep the compiler from moving
+            // the reads of other lanes' elements above the writes (and the next writes above the reads)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 3) {
+                const unsigned int n = c - t0 < (unsigned)kCentroidPiece ? c - t0 : (unsigned)kCentroidPiece;
+                const float* b = buf[wave][lane];
+                unsigned int i = 0;
+                for (; i + 4 <= n; i += 4) {
+                    const f32x4 q = *(const f32x4*)(b + i);
+                    s += q[0]; s += q[1]; s += q[2]; s += q[3];
+                }
+                for (; i < n; ++i) s += b[i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (lane < 3) out[3 * (size_t)v + lane] = s / (float)c;
+    }
+}
+
 } // namespace ccal
 
 extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
@@ -242,9 +302,17 @@ extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
                                           n_runs, rocprim::plus<unsigned int>(), st));
     // ---- centroids of all runs; the host drops each cloud's run of non-finite points (its last) -------
     CCAL_HIP(ctx, cent.ensure((size_t)n_runs * 3 * sizeof(float)));
-    hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, st, gathered.as<float>(),
-                       gathered.as<float>() + N, gathered.as<float>() + 2 * N, counts.as<unsigned int>(),
-                       offsets.as<unsigned int>(), n_runs, cent.as<float>());
+    // long runs (coarse leaves): a wave per run; short ones: a lane per run
+    if (n_runs > 0 && N / n_runs >= 64) {
+        const unsigned int groups = std::min<unsigned int>((n_runs + kCentroidWaves - 1) / kCentroidWaves, 256u * 8u);
+        hipLaunchKernelGGL(voxel_centroid_wave_kernel, dim3(groups), dim3(64 * kCentroidWaves), 0, st,
+                           gathered.as<float>(), gathered.as<float>() + N, gathered.as<float>() + 2 * N,
+                           counts.as<unsigned int>(), offsets.as<unsigned int>(), n_runs, cent.as<float>());
+    } else {
+        hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, st, gathered.as<float>(),
+                           gathered.as<float>() + N, gathered.as<float>() + 2 * N, counts.as<unsigned int>(),
+                           offsets.as<unsigned int>(), n_runs, cent.as<float>());
+    }
     CCAL_HIP(ctx, hipGetLastError());
     std::vector<float> all((size_t)n_runs * 3);
     std::vector<unsigned long long> run_key(n_runs);

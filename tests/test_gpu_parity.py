@@ -106,7 +106,7 @@ def test_device_voxel_grid_matches_oracle(gpu_opt, oracle, calib1):
     clouds.append(dirty)
     B = np.tile(np.eye(4), (4, 1, 1))
     gpu_opt.upload_clouds(1, clouds, B)
-    for leaf in (0.02, 0.005):
+    for leaf in (0.02, 0.005, 0.3):                    # 0.3: thousands of points per voxel (a wave per voxel)
         sizes = gpu_opt.downsample_raw(leaf)
         for j, c in enumerate(clouds):
             want = oracle.voxel_grid(c, leaf)
