@@ -352,6 +352,18 @@ constexpr size_t kStageThreshold = (size_t)192 << 20;
 constexpr int kStageLanes = 8;
 constexpr int kStageBatches = 8;
 
+// Stride of the fast path's point order (fast_slot_source): the integer nearest n / golden ratio or the
+// next one above it that is coprime to n.
+static int64_t fast_slot_stride(int64_t n)
+{
+    if (n <= 2) return 1;
+    auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+    int64_t s = (int64_t)((double)n * 0.6180339887498949);
+    if (s < 1) s = 1;
+    while (gcd(s, n) != 1) ++s;      // n - 1 is coprime to n: the loop ends below n
+    return s;
+}
+
 template <typename TileBatch>
 static hipError_t stage_clouds(ccal_ctx* ctx, int n_clouds, const float* const* xyz, const size_t* n_pts,
                                const std::vector<int64_t>& pt_off, float* stage, TileBatch tile_batch)
@@ -564,7 +576,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             for (int j = j0; j < j1; ++j) {
                 const float* src = stage.as<float>() + 3 * (size_t)pt_off[j];
                 hipLaunchKernelGGL(tile_cloud_kernel, dim3((unsigned)((n_pts[j] + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   src, (int64_t)n_pts[j], pt_off[j], (int64_t)cs.group_off[j],
+                                   src, (int64_t)n_pts[j], fast_slot_stride((int64_t)n_pts[j]), pt_off[j], (int64_t)cs.group_off[j],
                                    cs.centres_dev.as<double>() + 3 * (size_t)j, cs.xs.as<float>(), cs.ys.as<float>(),
                                    cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j,
                                    radius_sums_dev.as<float>() + rblock_off[j]);

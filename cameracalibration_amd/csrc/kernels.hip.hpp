@@ -98,8 +98,18 @@ __global__ __launch_bounds__(256) void centre_final_kernel(const double* __restr
     centres[t] = (s - s == 0.0) ? s : 0.0;
 }
 
+// The exact path's arrays keep the caller's point order.  The fast path's groups do not: slot i holds point
+// (i * stride) mod n, stride coprime to n and close to n / golden ratio, so that the points a wave works
+// on together come from all over the cloud.  Every fast kernel sums over all points of a cloud and is
+// indifferent to their order, except for speed: the histogram pass sends points whose residuals fall
+// into the same bin to the same LDS word, and neighbours in scan or voxel order do that all the time.
+__host__ __device__ inline int64_t fast_slot_source(int64_t i, int64_t n, int64_t stride)
+{
+    return (int64_t)(((unsigned long long)i * (unsigned long long)stride) % (unsigned long long)n);
+}
+
 __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict__ aos /* this cloud */,
-                                                         int64_t n, int64_t first_point, int64_t first_group,
+                                                         int64_t n, int64_t stride, int64_t first_point, int64_t first_group,
                                                          const double* __restrict__ centre /* this cloud */,
                                                          float* __restrict__ xs, float* __restrict__ ys,
                                                          float* __restrict__ zs, float* __restrict__ groups,
@@ -120,11 +130,13 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
         float* gp = groups + g * 256;
         // lane l = k*16 + col holds coordinate k; component u selects the tile
         const float dx = (float)((double)x - cx), dy = (float)((double)y - cy), dz = (float)((double)z - cz);
-        gp[(0 * 16 + col) * 4 + u] = dx;
-        gp[(1 * 16 + col) * 4 + u] = dy;
-        gp[(2 * 16 + col) * 4 + u] = dz;
-        gp[(3 * 16 + col) * 4 + u] = 1.0f;
         r2 = dx * dx + dy * dy + dz * dz;
+        const int64_t src = fast_slot_source(i, n, stride);
+        const float sx = aos[3 * src + 0], sy = aos[3 * src + 1], sz = aos[3 * src + 2];
+        gp[(0 * 16 + col) * 4 + u] = (float)((double)sx - cx);
+        gp[(1 * 16 + col) * 4 + u] = (float)((double)sy - cy);
+        gp[(2 * 16 + col) * 4 + u] = (float)((double)sz - cz);
+        gp[(3 * 16 + col) * 4 + u] = 1.0f;
     }
     // largest squared distance from the centre: non-negative floats order like their bit patterns,
     // and a NaN's pattern lies above infinity's, so a non-finite point leaves a non-finite mark
