@@ -24,3 +24,7 @@ pass write $SHORT -- WRITE_SIZE || exit 1
 pass issue $SHORT -- SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU || exit 1
 pass clock $SHORT -- GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MISS_sum || exit 1
 python3 tools/summarize_pmc.py $OUT > $OUT/summary.json && echo "[profile] summary written"
+echo "[profile] ingest kernels at 100 clouds x 1e6 points (voxel grid, point report, plane fit)"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ingest_vox -o t -- python3 tools/probe_voxel.py 100 1000000 > $OUT/ingest_vox.log 2> $OUT/ingest_vox.err || { echo "ingest voxel trace failed"; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ingest_fit -o t -- python3 tools/probe_fit.py 100 1000000 > $OUT/ingest_fit.log 2> $OUT/ingest_fit.err || { echo "ingest fit trace failed"; exit 1; }
+echo "[profile] done"

@@ -21,4 +21,8 @@ for key, name in (("residual", "r2_pmc_residual_kernel.json"), ("split_chain", "
         rec = dict(k[key])
         rec["command"] = summary["command"]
         json.dump(rec, open(os.path.join(dst, name), "w"), indent=1)
+for tag in ("ingest_vox", "ingest_fit"):
+    f = os.path.join(src, tag, "t_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "r2_%s_kernel_stats.csv" % tag))
 print("published to", dst)
