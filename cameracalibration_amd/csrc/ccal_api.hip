@@ -356,7 +356,7 @@ constexpr int kStageBatches = 8;
 // next one above it that is coprime to n.
 static int64_t fast_slot_stride(int64_t n)
 {
-    if (n <= 2) return 1;
+    if (n <= 2 || n >= ((int64_t)1 << 32)) return 1;     // slot * stride must stay below 2^64
     auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
     int64_t s = (int64_t)((double)n * 0.6180339887498949);
     if (s < 1) s = 1;
