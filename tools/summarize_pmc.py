@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Mean per launch of every counter rocprofv3 collected, per kernel, over the pmc_* directories of
-one tools/profile_r2.sh run, plus the figures DESIGN.md and bench.py quote (HBM bytes per launch with
+one tools/profile_r2.sh run, plus the figures the design notes and bench.py quote (HBM bytes per launch with
 the gfx950 correction of the MI355X guide, VALU instructions per (pose, point) of the part kernel,
 LDS instructions and bank-conflict share of the separable kernel).  Prints one JSON object."""
 import collections
