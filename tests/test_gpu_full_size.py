@@ -143,6 +143,45 @@ def test_c3_size_search_and_objective(gpu_opt, ccal, oracle, huge):
     np.testing.assert_array_equal(mx, omx)
 
 
+def test_full_size_point_report_and_cost_sweep(gpu_opt, ccal, oracle, huge):
+    """The two large result arrays of the path at 10^8 points: the per-point report (800 MB of distances +
+    100 MB of classes, copied out through the pinned staging lanes) against the per-cloud report of the
+    same pose and against the oracle on slices of three clouds; and a 6*10^7-candidate cost sweep (240 MB)
+    against the same sweep taken in pieces small enough for plain copies."""
+    s = huge
+    gpu_opt.upload_clouds(1, s.clouds, s.base_T_flange)
+    gpu_opt.upload_clouds(0, s.clouds, s.base_T_flange)
+    gpu_opt.set_plane(s.plane)
+    pose = s.pose_init.copy()
+    d, c = gpu_opt.point_errors(pose, which=1)
+    assert d.shape == (10 ** 8,) and c.shape == (10 ** 8,)
+    _, mean, mx = gpu_opt.per_cloud_error(pose, which=1)
+    off = np.cumsum([0] + [len(x) for x in s.clouds])
+    for j in (0, 37, 99):
+        part = d[off[j]:off[j + 1]]
+        assert part.max() == mx[j]
+        assert mean[j] == pytest.approx(part.mean(), rel=1e-12)
+        # a slice across a chunk boundary of the copy (8 MiB = 2^20 doubles), bit for bit against the oracle
+        lo, hi = 499_000, 501_000
+        o = oracle.OracleScene([s.clouds[j][lo:hi]], s.base_T_flange[j:j + 1])
+        want_d, want_c = o.point_errors(pose, s.plane.astype(np.float64), 0)
+        np.testing.assert_array_equal(part[lo:hi], want_d)
+        np.testing.assert_array_equal(c[off[j] + lo:off[j] + hi], want_c)
+    # classes agree with the distances everywhere: below 2.5 mm -> 0, below 5 mm -> 1, below 10 mm -> 2, else 3
+    mm = d * 1000.0
+    np.testing.assert_array_equal(c, ((mm >= 2.5).astype(np.uint8) + (mm >= 5.0) + (mm >= 10.0)).astype(c.dtype))
+
+    g = grid_of(ccal, [20, 20, 25, 20, 20, 25])
+    gpu_opt.set_search_mode(1)
+    try:
+        begin, end = 12_345_678, 72_345_678
+        whole = gpu_opt.grid_costs(pose, g, begin, end)
+        for b in (begin, begin + 29_999_999, end - 5_000_000):
+            np.testing.assert_array_equal(whole[b - begin:b - begin + 5_000_000], gpu_opt.grid_costs(pose, g, b, b + 5_000_000))
+    finally:
+        gpu_opt.set_search_mode(0)
+
+
 def test_c4_size_search(gpu_opt, ccal, oracle, huge):
     """100 clouds x 10^6 points, (20,20,25 | 20,20,25) = 10^8 candidates (10^16 residuals): the whole grid by
     the separable pass, the same grid as two shards merged, and a dense cut of 10^5 candidates around the
