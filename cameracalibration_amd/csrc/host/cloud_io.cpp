@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 
@@ -81,6 +82,140 @@ bool host_is_little_endian()
     return *reinterpret_cast<const unsigned char*>(&one) == 1;
 }
 
+// A byte buffer that is not cleared before the file is read into it.
+class RawBytes {
+public:
+    explicit RawBytes(size_t n) : p_(new unsigned char[n ? n : 1]), n_(n) {}
+    unsigned char* data() const { return p_.get(); }
+    size_t size() const { return n_; }
+private:
+    std::unique_ptr<unsigned char[]> p_;
+    size_t n_;
+};
+
+// x, y, z of `count` fixed-size records (or of three separate columns: any strides) into out.  Plain
+// 4-byte floats in host byte order -- what every depth camera writes -- are copied; anything else goes
+// through the generic scalar loader.
+struct Column { const unsigned char* base; size_t stride; int size; char kind; };
+void gather_xyz(const Column c[3], size_t count, bool swap, Cloud& out)
+{
+    const size_t at = out.size();
+    out.resize(at + 3 * count);
+    float* dst = out.data() + at;
+    const bool plain = !swap && c[0].size == 4 && c[1].size == 4 && c[2].size == 4 && c[0].kind == 'f' &&
+                       c[1].kind == 'f' && c[2].kind == 'f';
+    if (plain) {
+        const unsigned char *px = c[0].base, *py = c[1].base, *pz = c[2].base;
+        for (size_t r = 0; r < count; ++r, px += c[0].stride, py += c[1].stride, pz += c[2].stride) {
+            std::memcpy(dst + 3 * r + 0, px, 4);
+            std::memcpy(dst + 3 * r + 1, py, 4);
+            std::memcpy(dst + 3 * r + 2, pz, 4);
+        }
+        return;
+    }
+    for (size_t r = 0; r < count; ++r)
+        for (int k = 0; k < 3; ++k)
+            dst[3 * r + k] = (float)load_scalar(c[k].base + r * c[k].stride, c[k].size, c[k].kind, swap);
+}
+
+// strtof's value for the number at p, without its cost in the common case.  A decimal with at most 19
+// significant digits and a decimal exponent within +-22 is one exact integer times or over one exact power
+// of ten: a single correctly rounded double operation (Clinger's fast path).  Rounding that double to
+// float is the correctly rounded float of the decimal unless the double sits within one unit of a
+// midpoint between two floats, where the two roundings could disagree; that case, and everything
+// unusual (more digits, large exponents, inf/nan/hex, no digits at all), is left to strtof itself.
+float parse_float(const char* p, char** end)
+{
+    static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                      1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* q = p;
+    while (*q == ' ' || (*q >= '\t' && *q <= '\r')) ++q;
+    const char* start = q;
+    bool neg = false;
+    if (*q == '+' || *q == '-') neg = *q++ == '-';
+    uint64_t m = 0;
+    int digits = 0, dropped_exp = 0, frac = 0;
+    bool any = false;
+    for (; *q >= '0' && *q <= '9'; ++q) {
+        any = true;
+        if (digits < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++digits; }
+        else ++dropped_exp, digits = 20;
+    }
+    if (*q == '.') {
+        ++q;
+        for (; *q >= '0' && *q <= '9'; ++q) {
+            any = true;
+            if (digits < 19) { m = m * 10 + (uint64_t)(*q - '0'); if (m) ++digits; ++frac; }
+            else digits = 20;
+        }
+    }
+    if (!any || digits > 19) return std::strtof(p, end);
+    int e10 = dropped_exp - frac;
+    if (*q == 'e' || *q == 'E') {
+        const char* r = q + 1;
+        bool eneg = false;
+        if (*r == '+' || *r == '-') eneg = *r++ == '-';
+        if (*r >= '0' && *r <= '9') {
+            int ev = 0;
+            for (; *r >= '0' && *r <= '9'; ++r) ev = ev < 10000 ? ev * 10 + (*r - '0') : ev;
+            e10 += eneg ? -ev : ev;
+            q = r;
+        }
+    } else if (*q == 'x' || *q == 'X' || *q == 'p' || *q == 'P') {
+        return std::strtof(p, end);          // a hexadecimal float ("0x...")
+    }
+    if (m > ((uint64_t)1 << 53) || e10 < -22 || e10 > 22) return std::strtof(p, end);
+    double d = (double)m;
+    d = e10 < 0 ? d / kPow10[-e10] : d * kPow10[e10];
+    uint64_t bits;
+    std::memcpy(&bits, &d, 8);
+    const uint64_t low = bits & (((uint64_t)1 << 29) - 1);          // the bits a float drops
+    const uint64_t half = (uint64_t)1 << 28;
+    const int biased = (int)((bits >> 52) & 0x7ff);
+    // float's normal range only (below it the dropped bits are more), and not next to a midpoint
+    if (m != 0 && (biased < 1023 - 126 || biased > 1023 + 127 || (low >= half - 1 && low <= half + 1)))
+        return std::strtof(p, end);
+    (void)start;
+    if (end) *end = const_cast<char*>(q);
+    const float f = (float)d;
+    return neg ? -f : f;
+}
+
+// The rest of a stream as one string (a terminating NUL follows it, as c_str() guarantees).
+std::string slurp(std::ifstream& f)
+{
+    std::string body;
+    const std::streampos at = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streampos end = f.tellg();
+    f.seekg(at);
+    if (end > at) {
+        body.resize((size_t)(end - at));
+        f.read(&body[0], (std::streamsize)body.size());
+        body.resize((size_t)f.gcount());
+    }
+    return body;
+}
+
+// One text line of whitespace-separated columns: the floats of the three wanted columns.  Lines end at
+// '\n' (a '\r' before it counts as whitespace).  Returns the start of the next line, or nullptr when the
+// line has fewer columns than `need`.
+const char* parse_columns(const char* p, const char* body_end, const int want[3], int need, float v[3])
+{
+    int col = 0;
+    while (true) {
+        while (p < body_end && *p != '\n' && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+        if (p >= body_end || *p == '\n') break;
+        const char* tok = p;
+        while (p < body_end && !(*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+        for (int k = 0; k < 3; ++k)
+            if (want[k] == col) v[k] = parse_float(tok, nullptr);
+        ++col;
+    }
+    if (col < need) return nullptr;
+    return p < body_end ? p + 1 : p;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -140,15 +275,20 @@ Cloud read_ply(const std::string& filename)
         if (is_vertex && (ix < 0 || iy < 0 || iz < 0))
             throw std::runtime_error(filename + ": vertex element without x/y/z");
         if (ascii) {
+            if (!is_vertex) {
+                for (size_t r = 0; r < e.count; ++r)
+                    if (!std::getline(f, line)) throw std::runtime_error(filename + ": truncated PLY body");
+                continue;
+            }
+            const std::string body = slurp(f);
+            const char *p = body.c_str(), *body_end = p + body.size();
+            const int want[3] = {ix, iy, iz};
+            const int need = std::max(ix, std::max(iy, iz)) + 1;
+            out.resize(3 * e.count);
             for (size_t r = 0; r < e.count; ++r) {
-                if (!std::getline(f, line)) throw std::runtime_error(filename + ": truncated PLY body");
-                if (!is_vertex) continue;
-                auto t = split_ws(line);
-                if ((int)t.size() <= std::max(ix, std::max(iy, iz)))
-                    throw std::runtime_error(filename + ": short vertex line");
-                out.push_back(std::strtof(t[ix].c_str(), nullptr));
-                out.push_back(std::strtof(t[iy].c_str(), nullptr));
-                out.push_back(std::strtof(t[iz].c_str(), nullptr));
+                if (p >= body_end) throw std::runtime_error(filename + ": truncated PLY body");
+                p = parse_columns(p, body_end, want, need, out.data() + 3 * r);
+                if (!p) throw std::runtime_error(filename + ": short vertex line");
             }
         } else {
             if (has_list) {
@@ -158,17 +298,14 @@ Cloud read_ply(const std::string& filename)
                 if (!out.empty()) break;
                 throw std::runtime_error(filename + ": list element before the vertices");
             }
-            std::vector<unsigned char> buf((size_t)rec * e.count);
+            const RawBytes buf((size_t)rec * e.count);
             f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
             if ((size_t)f.gcount() != buf.size()) throw std::runtime_error(filename + ": truncated PLY body");
             if (!is_vertex) continue;
-            out.reserve(out.size() + 3 * e.count);
-            for (size_t r = 0; r < e.count; ++r) {
-                const unsigned char* p = buf.data() + r * (size_t)rec;
-                out.push_back((float)load_scalar(p + offs[ix], e.props[ix].size, e.props[ix].kind, swap));
-                out.push_back((float)load_scalar(p + offs[iy], e.props[iy].size, e.props[iy].kind, swap));
-                out.push_back((float)load_scalar(p + offs[iz], e.props[iz].size, e.props[iz].kind, swap));
-            }
+            const Column cols[3] = {{buf.data() + offs[ix], (size_t)rec, e.props[ix].size, e.props[ix].kind},
+                                    {buf.data() + offs[iy], (size_t)rec, e.props[iy].size, e.props[iy].kind},
+                                    {buf.data() + offs[iz], (size_t)rec, e.props[iz].size, e.props[iz].kind}};
+            gather_xyz(cols, e.count, swap, out);
         }
         if (is_vertex) break;
     }
@@ -257,27 +394,25 @@ Cloud read_pcd(const std::string& filename)
         return t == 'I' ? 'i' : 'u';
     };
     Cloud out;
-    out.reserve(points * 3);
     if (data == "ascii") {
+        const std::string body = slurp(f);
+        const char *p = body.c_str(), *body_end = p + body.size();
+        const int want[3] = {cols[ix], cols[iy], cols[iz]};
+        out.resize(points * 3);
         for (size_t r = 0; r < points; ++r) {
-            if (!std::getline(f, line)) throw std::runtime_error(filename + ": truncated PCD body");
-            auto t = split_ws(line);
-            if ((int)t.size() < col) throw std::runtime_error(filename + ": short PCD line");
-            out.push_back(std::strtof(t[cols[ix]].c_str(), nullptr));
-            out.push_back(std::strtof(t[cols[iy]].c_str(), nullptr));
-            out.push_back(std::strtof(t[cols[iz]].c_str(), nullptr));
+            if (p >= body_end) throw std::runtime_error(filename + ": truncated PCD body");
+            p = parse_columns(p, body_end, want, col, out.data() + 3 * r);
+            if (!p) throw std::runtime_error(filename + ": short PCD line");
         }
     } else if (data == "binary") {
-        std::vector<unsigned char> buf((size_t)rec * points);
+        const RawBytes buf((size_t)rec * points);
         f.read(reinterpret_cast<char*>(buf.data()), (std::streamsize)buf.size());
         if ((size_t)f.gcount() != buf.size()) throw std::runtime_error(filename + ": truncated PCD body");
         const bool swap = !host_is_little_endian();
-        for (size_t r = 0; r < points; ++r) {
-            const unsigned char* p = buf.data() + r * (size_t)rec;
-            out.push_back((float)load_scalar(p + offs[ix], sizes[ix], kind_of(ix), swap));
-            out.push_back((float)load_scalar(p + offs[iy], sizes[iy], kind_of(iy), swap));
-            out.push_back((float)load_scalar(p + offs[iz], sizes[iz], kind_of(iz), swap));
-        }
+        const Column c3[3] = {{buf.data() + offs[ix], (size_t)rec, sizes[ix], kind_of(ix)},
+                              {buf.data() + offs[iy], (size_t)rec, sizes[iy], kind_of(iy)},
+                              {buf.data() + offs[iz], (size_t)rec, sizes[iz], kind_of(iz)}};
+        gather_xyz(c3, points, swap, out);
     } else if (data == "binary_compressed") {
         // PCL's writer: uint32 compressed size, uint32 uncompressed size, an LZF stream; the
         // uncompressed body holds the fields one after the other (all points' values of field 0,
@@ -288,19 +423,18 @@ Cloud read_pcd(const std::string& filename)
         auto u32 = [](const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); };
         const size_t n_comp = u32(sz), n_raw = u32(sz + 4);
         if (n_raw != (size_t)rec * points) throw std::runtime_error(filename + ": PCD compressed body has the wrong size");
-        std::vector<unsigned char> comp(n_comp), buf(n_raw);
+        const RawBytes comp(n_comp), buf(n_raw);
         f.read(reinterpret_cast<char*>(comp.data()), (std::streamsize)n_comp);
         if ((size_t)f.gcount() != n_comp) throw std::runtime_error(filename + ": truncated PCD body");
         if (!lzf_decompress(comp.data(), n_comp, buf.data(), n_raw))
             throw std::runtime_error(filename + ": malformed LZF stream in the PCD body");
         const bool swap = !host_is_little_endian();
         // field i starts at points * (bytes of the fields before it)
-        auto column = [&](int i, size_t r) { return buf.data() + points * (size_t)offs[i] + r * (size_t)(sizes[i] * counts[i]); };
-        for (size_t r = 0; r < points; ++r) {
-            out.push_back((float)load_scalar(column(ix, r), sizes[ix], kind_of(ix), swap));
-            out.push_back((float)load_scalar(column(iy, r), sizes[iy], kind_of(iy), swap));
-            out.push_back((float)load_scalar(column(iz, r), sizes[iz], kind_of(iz), swap));
-        }
+        auto column = [&](int i) {
+            return Column{buf.data() + points * (size_t)offs[i], (size_t)(sizes[i] * counts[i]), sizes[i], kind_of(i)};
+        };
+        const Column c3[3] = {column(ix), column(iy), column(iz)};
+        gather_xyz(c3, points, swap, out);
     } else {
         throw std::runtime_error(filename + ": unsupported PCD DATA '" + data + "'");
     }
@@ -327,7 +461,7 @@ Cloud read_xyz_text(const std::string& filename, double scale)
             size_t comma = tok.find(',', pos);
             std::string piece = tok.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
             char* endp = nullptr;
-            float s = std::strtof(piece.c_str(), &endp);
+            float s = parse_float(piece.c_str(), &endp);
             if (endp == piece.c_str()) throw std::runtime_error(filename + ": malformed xyz coordinate");
             v[k] = (float)((double)s / scale);
             pos = comma == std::string::npos ? tok.size() : comma + 1;

@@ -166,6 +166,52 @@ def test_xyz_reader(ccal, pts, tmp_path):
     np.testing.assert_array_equal(got, want)
 
 
+def test_ascii_numbers_are_strtof_values(ccal, tmp_path):
+    """The text readers take a decimal to the float strtof gives (the reference reads with stof and PCL's
+    stream extraction): short and long digit strings, exponents, values next to float midpoints (where
+    rounding through double would go wrong), denormals, overflow, signed zeros, inf/nan, hex floats."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.strtof.restype = ctypes.c_float
+    libc.strtof.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    rng = np.random.default_rng(99)
+    toks = ["0", "-0", "-0.0", "+1", "1.", ".5", "-.25e1", "1e0", "1E+2", "1e-3", "3.4028235e38", "3.4028236e38", "1e39",
+            "1e-45", "7e-46", "1.17549435e-38", "1.1754942e-38", "123456789012345678901234567890", "0.1", "0.3",
+            "16777217", "16777217.0000000001", "33554434.000", "9007199254740993", "1.00000005960464477539",
+            "1.00000005960464477540", "1.0000000596046447753906250", "0.000000000000000000000012345", "12345e22", "12345e23",
+            "inf", "-inf", "nan", "0x1.8p1", "1e", "1e+", "5e-324", "1.5abc", "00012.50"]
+    # midpoints between adjacent floats and their decimal neighbours
+    for _ in range(200):
+        f = np.float32(rng.uniform(-2, 2) * 10.0 ** rng.integers(-6, 7))
+        g = np.nextafter(f, np.float32(np.inf), dtype=np.float32)
+        mid = (float(f) + float(g)) / 2.0
+        toks += [repr(mid), "%.17g" % mid, "%.20g" % np.nextafter(mid, np.inf), "%.12g" % mid, "%.9g" % f, "%.6e" % f]
+    for _ in range(3000):
+        digits = int(rng.integers(1, 18))
+        m = int(rng.integers(0, 10 ** digits))
+        frac = int(rng.integers(0, digits + 1))
+        t = str(m).rjust(frac + 1, "0")
+        t = (t[:-frac] + "." + t[-frac:]) if frac else t
+        if rng.random() < 0.3:
+            t += "e%d" % int(rng.integers(-30, 30))
+        toks.append(("-" if rng.random() < 0.3 else "") + t)
+    toks += [toks[-1]] * ((3 - len(toks) % 3) % 3)
+    want = np.array([libc.strtof(t.encode(), None) for t in toks], dtype=np.float32).reshape(-1, 3)
+    n = len(want)
+    rows = [" ".join(toks[3 * i:3 * i + 3]) for i in range(n)]
+    ply = str(tmp_path / "n_1.ply")
+    with open(ply, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\nend_header\n" % n)
+        f.write("\n".join(rows) + "\n")
+    pcd = str(tmp_path / "n_1.pcd")
+    with open(pcd, "w") as f:
+        f.write("VERSION .7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH %d\nHEIGHT 1\nPOINTS %d\nDATA ascii\n" % (n, n))
+        f.write("\r\n".join(rows) + "\n")                       # CRLF line ends too
+    for path in (ply, pcd):
+        got = ccal.read_point_cloud(path)
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_unsupported_and_missing_files(ccal, tmp_path):
     with pytest.raises(ccal.CcalError):
         ccal.read_point_cloud(str(tmp_path / "nope_1.ply"))
