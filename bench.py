@@ -45,11 +45,13 @@ MATRIX_FLOP_PER_RESIDUAL = {      # what the matrix pipe executes per residual
     "bf16x3": 2 * 32,             # one 16x16x32 bf16 MFMA (16384 FLOP) per 256 residuals
     "f32": 2 * 4,                 # one 16x16x4 f32 MFMA (2048 FLOP) per 256 residuals
     "bf16x3wide": 2 * 32,         # two 32x32x16 bf16 MFMAs per 1024 residuals
+    "bf16x3n8": 2 * 32,           # the 16x16x32 kernel with 8 candidate tiles per wave
 }
-MATRIX_PEAK_TFLOPS = {"bf16x3": PEAK_BF16_TFLOPS, "f32": PEAK_FP32_TFLOPS, "bf16x3wide": PEAK_BF16_TFLOPS}
+MATRIX_PEAK_TFLOPS = {"bf16x3": PEAK_BF16_TFLOPS, "f32": PEAK_FP32_TFLOPS, "bf16x3wide": PEAK_BF16_TFLOPS,
+                      "bf16x3n8": PEAK_BF16_TFLOPS}
 KERNEL_NAME = {"bf16x3": "residual_bf16x3_kernel", "f32": "residual_mfma_kernel",
-               "bf16x3wide": "residual_bf16x3_wide_kernel"}
-KERNEL_KIND = {"bf16x3": 0, "f32": 1, "bf16x3wide": 2}
+               "bf16x3wide": "residual_bf16x3_wide_kernel", "bf16x3n8": "residual_bf16x3_kernel"}
+KERNEL_KIND = {"bf16x3": 0, "f32": 1, "bf16x3wide": 2, "bf16x3n8": 3}
 # VALU instructions the part kernel of the exact path executes per (pose, point), from the
 # SQ_INSTS_VALU counter of the committed PMC pass (profiles/): the unit of the GD leg's roofline
 EXACT_VALU_PER_POINT_FILE = os.path.join(ROOT, "profiles", "r2_pmc_split_chain_kernel.json")
@@ -87,7 +89,7 @@ def parse():
     ap.add_argument("--axis", type=int, default=10, help="grid steps per axis (10 -> 10^6 candidates)")
     ap.add_argument("--cpu-candidates", type=int, default=512,
                     help="candidates of the workload scored by the CPU oracle for cpu_baseline (0 = skip)")
-    ap.add_argument("--kernel", choices=["bf16x3", "f32", "bf16x3wide"], default="bf16x3",
+    ap.add_argument("--kernel", choices=["bf16x3", "f32", "bf16x3wide", "bf16x3n8"], default="bf16x3",
                     help="fast-path kernel: exact bf16x3 operand split on the bf16 matrix pipe, or FP32-input MFMA")
     ap.add_argument("--gd-iterations", type=int, default=-1,
                     help="iteration cap of the untimed GD refinement (-1 = reference's 10000, 0 = skip)")
@@ -145,7 +147,7 @@ def main():
     opt = cc.Optimizer(dev_index)
     opt.upload_clouds(cc.CCAL_DOWNSAMPLED, scene.clouds, scene.base_T_flange)
     opt.set_plane(scene.plane)
-    opt.set_fast_kernel({"bf16x3": 0, "f32": 1, "bf16x3wide": 2}[args.kernel])
+    opt.set_fast_kernel(KERNEL_KIND[args.kernel])
 
     if args.workload == "c3":
         # one grid for the whole job, (20,20,25 | 10,10,10) = 10^7 candidates, contiguous shards

@@ -129,11 +129,13 @@ struct FastLaunch {
     int n_splits;
 };
 
-FastLaunch plan_fast(const ccal_ctx* ctx, const CloudSet& cs, int64_t n)
+// per_block: candidates of one workgroup of the kernel the plan is for (kCandPerBlock for kernels that
+// give a wave 8 candidate tiles, twice that for 16).
+FastLaunch plan_fast(const ccal_ctx* ctx, const CloudSet& cs, int64_t n, int64_t per_block)
 {
     FastLaunch f;
-    f.cand_blocks = (n + kCandPerBlock - 1) / kCandPerBlock;
-    f.n_padded = f.cand_blocks * kCandPerBlock;
+    f.cand_blocks = (n + per_block - 1) / per_block;
+    f.n_padded = f.cand_blocks * per_block;
     f.n_ctiles = (int)(f.n_padded / 16);
     f.n_splits = choose_splits(ctx, cs, f.cand_blocks);
     return f;
@@ -146,8 +148,8 @@ int64_t fast_chunk(const CloudSet& cs)
     const int64_t w_budget = (int64_t)4 << 30;  // 4 GiB of W per launch
     int64_t c = w_budget / (16 * (int64_t)cs.n_clouds);
     c = std::min<int64_t>(c, (int64_t)1 << 24);
-    c = std::max<int64_t>(c, kCandPerBlock);
-    return (c / kCandPerBlock) * kCandPerBlock;
+    c = std::max<int64_t>(c, 2 * kCandPerBlock);
+    return (c / (2 * kCandPerBlock)) * (2 * kCandPerBlock);
 }
 
 FoldConsts fold_consts(const float plane[4])
@@ -179,7 +181,8 @@ template <typename Source>
 int run_fast_chunk(ccal_ctx* ctx, const CloudSet& cs, const Source& src, int64_t n,
                    float* cost_dst, hipEvent_t ev0, hipEvent_t ev1)
 {
-    FastLaunch f = plan_fast(ctx, cs, n);
+    // the default kernel gives a wave 16 candidate tiles, the others 8
+    FastLaunch f = plan_fast(ctx, cs, n, ctx->fast_kernel == CCAL_FAST_BF16X3 ? 2 * kCandPerBlock : kCandPerBlock);
     CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)cs.n_clouds * f.n_ctiles * 64 * sizeof(float)));
     CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)f.n_splits * f.n_padded * sizeof(double)));
     const FoldConsts fc = fold_consts(ctx->plane);
@@ -200,8 +203,14 @@ int run_fast_chunk(ccal_ctx* ctx, const CloudSet& cs, const Source& src, int64_t
                            cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
                            cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
                            f.n_ctiles, f.n_splits);
+    else if (ctx->fast_kernel == CCAL_FAST_BF16X3_8)
+        hipLaunchKernelGGL((residual_bf16x3_kernel<kNA, 4>), dim3((unsigned)f.cand_blocks, f.n_splits),
+                           dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
+                           cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
+                           cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
+                           f.n_ctiles, f.n_splits);
     else
-        hipLaunchKernelGGL(residual_bf16x3_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
+        hipLaunchKernelGGL((residual_bf16x3_kernel<2 * kNA, 8>), dim3((unsigned)f.cand_blocks, f.n_splits),
                            dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(),
                            cs.groups.as<f32x4>(), cs.group_off_dev.as<int>(),
                            cs.scale_dev.as<double>(), ctx->partial_buf.as<double>(), cs.n_clouds,
@@ -747,9 +756,9 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
 extern "C" int ccal_set_fast_kernel(ccal_ctx* ctx, int kind)
 {
     if (!ctx) return CCAL_ERR_ARG;
-    if (kind != CCAL_FAST_BF16X3 && kind != CCAL_FAST_F32 && kind != CCAL_FAST_BF16X3_WIDE)
+    if (kind != CCAL_FAST_BF16X3 && kind != CCAL_FAST_F32 && kind != CCAL_FAST_BF16X3_WIDE && kind != CCAL_FAST_BF16X3_8)
         return fail(ctx, CCAL_ERR_ARG,
-                    "set_fast_kernel: kind must be CCAL_FAST_BF16X3, CCAL_FAST_F32 or CCAL_FAST_BF16X3_WIDE");
+                    "set_fast_kernel: kind must be CCAL_FAST_BF16X3, CCAL_FAST_F32, CCAL_FAST_BF16X3_WIDE or CCAL_FAST_BF16X3_8");
     ctx->fast_kernel = kind;
     if (kind == CCAL_FAST_BF16X3_WIDE) {
         if (int rc = bind(ctx)) return rc;

@@ -413,70 +413,76 @@ __device__ inline bf16x8 split_candidate_operand(float w, bool constant_group)
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// Promotes the FP32 lane accumulators of a wave into two FP64 totals per lane.
+// Promotes the FP32 lane accumulators of a wave into NA/4 FP64 totals per lane.
 // acc[a][r] of lane l belongs to candidate (l>>4)*4 + r of tile a and point column
-// l&15; the 16 lanes of a row are reduce-scattered (4 exchange steps), after which
-// lane column c owns the row totals of pairs 2c and 2c+1, pair = a*4 + r.
+// l&15; the 16 lanes of a row are reduce-scattered (4 exchange steps: every step a
+// lane keeps one half of its values and adds the partner's copy of that half), after
+// which lane column c owns NA/4 consecutive row totals, value = a*4 + r.
 template <int NA>
-__device__ inline void promote_rows(float (&acc)[NA][4], double scale, double& tot0, double& tot1)
+__device__ inline void promote_rows(float (&acc)[NA][4], double scale, double (&tot)[NA / 4])
 {
-    static_assert(NA == 8, "the reduce-scatter below is written for 32 values per lane");
+    static_assert(NA == 8 || NA == 16, "the reduce-scatter needs 4 NA values per lane to be a multiple of 16");
+    constexpr int V = 4 * NA;
     const int col = threadIdx.x & 15;
-    float v[32];
+    float v[V];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[a * 4 + r] = acc[a][r]; acc[a][r] = 0.f; }
-    // step with partner col^8: lanes with bit 3 clear keep values 0..15, others 16..31
-    float w16[16];
+    float w2[V / 2];
     {
         const bool hi = (col & 8) != 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float keep = hi ? v[16 + i] : v[i];
-            const float give = hi ? v[i] : v[16 + i];
-            w16[i] = keep + __shfl_xor(give, 8, 64);
+        for (int i = 0; i < V / 2; ++i) {
+            const float keep = hi ? v[V / 2 + i] : v[i];
+            const float give = hi ? v[i] : v[V / 2 + i];
+            w2[i] = keep + __shfl_xor(give, 8, 64);
         }
     }
-    float w8[8];
+    float w4[V / 4];
     {
         const bool hi = (col & 4) != 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float keep = hi ? w16[8 + i] : w16[i];
-            const float give = hi ? w16[i] : w16[8 + i];
-            w8[i] = keep + __shfl_xor(give, 4, 64);
+        for (int i = 0; i < V / 4; ++i) {
+            const float keep = hi ? w2[V / 4 + i] : w2[i];
+            const float give = hi ? w2[i] : w2[V / 4 + i];
+            w4[i] = keep + __shfl_xor(give, 4, 64);
         }
     }
-    float w4[4];
+    float w8[V / 8];
     {
         const bool hi = (col & 2) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float keep = hi ? w8[4 + i] : w8[i];
-            const float give = hi ? w8[i] : w8[4 + i];
-            w4[i] = keep + __shfl_xor(give, 2, 64);
+        for (int i = 0; i < V / 8; ++i) {
+            const float keep = hi ? w4[V / 8 + i] : w4[i];
+            const float give = hi ? w4[i] : w4[V / 8 + i];
+            w8[i] = keep + __shfl_xor(give, 2, 64);
         }
     }
     {
         const bool hi = (col & 1) != 0;
-        const float k0 = hi ? w4[2] : w4[0], g0 = hi ? w4[0] : w4[2];
-        const float k1 = hi ? w4[3] : w4[1], g1 = hi ? w4[1] : w4[3];
-        tot0 += (double)(k0 + __shfl_xor(g0, 1, 64)) * scale;
-        tot1 += (double)(k1 + __shfl_xor(g1, 1, 64)) * scale;
+#pragma unroll
+        for (int i = 0; i < V / 16; ++i) {
+            const float keep = hi ? w8[V / 16 + i] : w8[i];
+            const float give = hi ? w8[i] : w8[V / 16 + i];
+            tot[i] += (double)(keep + __shfl_xor(give, 1, 64)) * scale;
+        }
     }
 }
 
-// Pair index owned by lane column c after promote_rows: bit 3 of c selects the
-// upper 16 values, bit 2 the upper 8 of those, bit 1 the upper 4, bit 0 the upper 2;
-// the two totals are consecutive values of that quad-pair.
-__device__ inline int promoted_pair(int col, int which)
+// Value index (a*4 + r) of total `which` of lane column c after promote_rows: bit 3 of c selects the
+// upper half of the 4 NA values, bit 2 the upper half of that, and so on; the totals are consecutive.
+template <int NA>
+__device__ inline int promoted_value(int col, int which)
 {
-    return ((col & 8) ? 16 : 0) + ((col & 4) ? 8 : 0) + ((col & 2) ? 4 : 0) + ((col & 1) ? 2 : 0) + which;
+    constexpr int V = 4 * NA;
+    return ((col & 8) ? V / 2 : 0) + ((col & 4) ? V / 4 : 0) + ((col & 2) ? V / 8 : 0) + ((col & 1) ? V / 16 : 0) + which;
 }
 
-template <int NA>
-__global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
+// NA = candidate tiles per wave: 8 (three waves per SIMD) or 16 (two: the split of a point tile and its
+// load are shared by twice as many matrix instructions).
+template <int NA, int kBurst = 4>
+__global__ __launch_bounds__(256, NA == 16 ? 2 : 3) void residual_bf16x3_kernel(
     const float* __restrict__ W, const f32x4* __restrict__ groups,
     const int* __restrict__ group_off, const double* __restrict__ scale,
     double* __restrict__ partial, int n_clouds, int n_ctiles, int n_splits)
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
     const int ctile0 = (blockIdx.x * 4 + wave) * NA;
     const int split = blockIdx.y;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    double tot0 = 0.0, tot1 = 0.0;
+    double tot[NA / 4] = {};
 
     for (int j = 0; j < n_clouds; ++j) {
         const int g0 = group_off[j];
@@ -512,7 +518,6 @@ __global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
         int since = 0;
         // Bursts: kBurst MFMAs back to back, then the |d| adds of the previous
         // burst; the bf16 split of the next point tile rides along with the adds.
-        constexpr int kBurst = 4;
         static_assert(NA % kBurst == 0, "candidate tiles per wave must be a multiple of the burst");
         bf16x8 Bc = split_point_operand(b[0]);
         f32x4 carry[kBurst];
@@ -548,24 +553,24 @@ __global__ __launch_bounds__(256, 3) void residual_bf16x3_kernel(
             b = bn;
             if (++since == kFlushGroups) {
                 since = 0;
-                promote_rows<NA>(acc, sc, tot0, tot1);
+                promote_rows<NA>(acc, sc, tot);
             }
         }
 #pragma unroll
         for (int q = 0; q < kBurst; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[NA - kBurst + q][r] += __builtin_fabsf(carry[q][r]);
-        promote_rows<NA>(acc, sc, tot0, tot1);
+        promote_rows<NA>(acc, sc, tot);
     }
 
     // lane (row, col) owns pairs p0, p0+1 of its row: candidate = tile a, row*4 + r
     double* out = partial + (int64_t)split * n_ctiles * 16;
     const int row = lane >> 4, col = lane & 15;
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const int pair = promoted_pair(col, which);
-        const int a = pair >> 2, r = pair & 3;
-        out[(int64_t)(ctile0 + a) * 16 + row * 4 + r] = which ? tot1 : tot0;
+    for (int which = 0; which < NA / 4; ++which) {
+        const int value = promoted_value<NA>(col, which);
+        const int a = value >> 2, r = value & 3;
+        out[(int64_t)(ctile0 + a) * 16 + row * 4 + r] = tot[which];
     }
 }
 

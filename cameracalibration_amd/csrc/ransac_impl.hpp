@@ -88,7 +88,7 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                        ctx->mats_buf.as<double>(), seed, n_hyp, ctx->rec_buf.as<double>());
 
     // 2. fast scoring of every (hypothesis, point) pair
-    FastLaunch f = plan_fast(ctx, cs, n_hyp);
+    FastLaunch f = plan_fast(ctx, cs, n_hyp, kCandPerBlock);
     CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)C * f.n_ctiles * 64 * sizeof(float)));
     CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)f.n_splits * f.n_padded * sizeof(unsigned long long)));
     CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_hyp * sizeof(unsigned long long)));

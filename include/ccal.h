@@ -132,12 +132,15 @@ int ccal_eval_bounded(ccal_ctx* ctx, int which, int n_poses, const double* poses
 /* Which kernel the fast path runs (no counterpart in the reference):
  *   CCAL_FAST_BF16X3 (default)  operands split exactly into three bf16 pieces,
  *                               contraction on the bf16 matrix pipe, FP32 accumulate;
+ *                               16 candidate tiles per wave (blocks of 1024 candidates);
  *   CCAL_FAST_F32               FP32-input matrix instruction (fmaf-chain exact);
  *   CCAL_FAST_BF16X3_WIDE       the bf16x3 contraction as pairs of 32x32x16 matrix
- *                               instructions on point operands split at upload.
+ *                               instructions on point operands split at upload;
+ *   CCAL_FAST_BF16X3_8          the default kernel with 8 candidate tiles per wave (three
+ *                               waves per SIMD instead of two; a few per cent slower).
  * All meet the same 1e-5 cost tolerance; the final arg-min never depends on it
  * (near-minimum candidates are re-scored with ccal_eval arithmetic). */
-enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1, CCAL_FAST_BF16X3_WIDE = 2 };
+enum { CCAL_FAST_BF16X3 = 0, CCAL_FAST_F32 = 1, CCAL_FAST_BF16X3_WIDE = 2, CCAL_FAST_BF16X3_8 = 3 };
 int ccal_set_fast_kernel(ccal_ctx* ctx, int kind);
 
 /* How ccal_grid_search scores the grid on the fast path (no counterpart in the reference;

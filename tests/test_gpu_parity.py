@@ -249,7 +249,7 @@ def test_exact_eval_with_caller_planes(gpu_opt, oracle):
         np.testing.assert_array_equal(gpu_opt.get_error(poses[:5], scaled), want)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_every_fast_kernel_meets_tolerance(gpu_opt, oracle, kind):
     """kind 0: exact bf16x3 operand split on the bf16 matrix pipe; kind 1: FP32-input MFMA;
     kind 2: the bf16x3 contraction as 32x32x16 pairs on operands split at upload."""
