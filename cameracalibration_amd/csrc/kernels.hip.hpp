@@ -389,7 +389,7 @@ __device__ inline void split_bf16x3(float v, unsigned& h, unsigned& m, unsigned&
     const float r1 = v - __uint_as_float(h);
     m = __float_as_uint(r1) & 0xffff0000u;
     const float r2 = r1 - __uint_as_float(m);
-    l = __float_as_uint(r2) & 0xffff0000u;
+    l = __float_as_uint(r2);      // what is left has at most 8 significant bits: already a bf16 value
 }
 
 // two bf16 given as FP32 bit patterns with zero low halves: low 16 bits = a, high = b
