@@ -65,12 +65,15 @@ struct VoxelDims {
 
 // One thread per point; the table of 4096-point blocks says which cloud a point belongs to.
 // key = cloud << cell_bits | cell; idx = the point's index in the whole set.
+// KeyT: 32 bits wide when cloud number and cell index fit (the usual case: the sort then moves 8 bytes
+// per point and pass instead of 12), else 64.
+template <typename KeyT>
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xs,
                                                          const float* __restrict__ ys,
                                                          const float* __restrict__ zs,
                                                          const BlockDesc* __restrict__ blocks,
                                                          const VoxelDims* __restrict__ dims, unsigned cell_bits,
-                                                         unsigned long long* __restrict__ keys,
+                                                         KeyT* __restrict__ keys,
                                                          unsigned int* __restrict__ idx)
 {
     const BlockDesc bd = blocks[blockIdx.x];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict
             const long long i2 = (long long)(floorf(z * d.inv) - d.minb[2]);
             key = (unsigned long long)(i0 + i1 * d.div0 + i2 * d.div01);
         }
-        keys[i] = ((unsigned long long)bd.cloud << cell_bits) | key;
+        keys[i] = (KeyT)(((unsigned long long)bd.cloud << cell_bits) | key);
         idx[i] = (unsigned int)i;
     }
 }
@@ -267,27 +270,29 @@ extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
     CCAL_HIP(ctx, gathered.ensure(3 * N * sizeof(float)));
     CCAL_HIP(ctx, dims_dev.ensure((size_t)C * sizeof(VoxelDims)));
     CCAL_HIP(ctx, hipMemcpyAsync(dims_dev.p, dims.data(), (size_t)C * sizeof(VoxelDims), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(voxel_keys_kernel, dim3(raw.n_blocks), dim3(256), 0, st, xs, ys, zs, raw.blocks.as<BlockDesc>(),
-                       dims_dev.as<VoxelDims>(), cell_bits, keys.as<unsigned long long>(), idx.as<unsigned int>());
-    size_t tmp_bytes = 0;
-    CCAL_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<unsigned long long>(),
-                                            keys2.as<unsigned long long>(), idx.as<unsigned int>(),
-                                            idx2.as<unsigned int>(), N, 0, cell_bits + cloud_bits, st));
-    CCAL_HIP(ctx, tmp.ensure(tmp_bytes));
-    CCAL_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<unsigned long long>(),
-                                            keys2.as<unsigned long long>(), idx.as<unsigned int>(),
-                                            idx2.as<unsigned int>(), N, 0, cell_bits + cloud_bits, st));
-    // the sorted keys are no longer needed once encoded: the run tables reuse the unsorted key array
-    // (runs <= points) -- uniq: N x 8 bytes
+    auto sort_and_encode = [&](auto key_tag) -> int {
+        using KeyT = decltype(key_tag);
+        hipLaunchKernelGGL(voxel_keys_kernel<KeyT>, dim3(raw.n_blocks), dim3(256), 0, st, xs, ys, zs, raw.blocks.as<BlockDesc>(),
+                           dims_dev.as<VoxelDims>(), cell_bits, keys.as<KeyT>(), idx.as<unsigned int>());
+        size_t tmp_bytes = 0;
+        CCAL_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.as<KeyT>(), keys2.as<KeyT>(), idx.as<unsigned int>(),
+                                                idx2.as<unsigned int>(), N, 0, cell_bits + cloud_bits, st));
+        CCAL_HIP(ctx, tmp.ensure(tmp_bytes));
+        CCAL_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.as<KeyT>(), keys2.as<KeyT>(), idx.as<unsigned int>(),
+                                                idx2.as<unsigned int>(), N, 0, cell_bits + cloud_bits, st));
+        // the sorted keys are no longer needed once encoded: the run tables reuse the unsorted key array
+        // (runs <= points)
+        size_t tmp2 = 0;
+        CCAL_HIP(ctx, rocprim::run_length_encode(nullptr, tmp2, keys2.as<KeyT>(), (unsigned int)N, uniq.as<KeyT>(),
+                                                 counts.as<unsigned int>(), nruns.as<unsigned int>(), st));
+        CCAL_HIP(ctx, tmp.ensure(tmp2));
+        CCAL_HIP(ctx, rocprim::run_length_encode(tmp.p, tmp2, keys2.as<KeyT>(), (unsigned int)N, uniq.as<KeyT>(),
+                                                 counts.as<unsigned int>(), nruns.as<unsigned int>(), st));
+        return CCAL_OK;
+    };
+    const bool narrow = cell_bits + cloud_bits <= 32;
     CCAL_HIP(ctx, uniq.ensure(N * 8)); CCAL_HIP(ctx, counts.ensure(N * 4)); CCAL_HIP(ctx, offsets.ensure(N * 4));
-    size_t tmp2 = 0;
-    CCAL_HIP(ctx, rocprim::run_length_encode(nullptr, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
-                                             uniq.as<unsigned long long>(), counts.as<unsigned int>(),
-                                             nruns.as<unsigned int>(), st));
-    CCAL_HIP(ctx, tmp.ensure(tmp2));
-    CCAL_HIP(ctx, rocprim::run_length_encode(tmp.p, tmp2, keys2.as<unsigned long long>(), (unsigned int)N,
-                                             uniq.as<unsigned long long>(), counts.as<unsigned int>(),
-                                             nruns.as<unsigned int>(), st));
+    if (int rc = narrow ? sort_and_encode((unsigned int)0) : sort_and_encode((unsigned long long)0)) return rc;
     hipLaunchKernelGGL(voxel_gather_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, xs, ys, zs,
                        idx2.as<unsigned int>(), (int64_t)N, gathered.as<float>(), gathered.as<float>() + N,
                        gathered.as<float>() + 2 * N);
@@ -316,9 +321,12 @@ extern "C" int ccal_downsample_raw(ccal_ctx* ctx, float leaf, size_t* n_pts_out)
     CCAL_HIP(ctx, hipGetLastError());
     std::vector<float> all((size_t)n_runs * 3);
     std::vector<unsigned long long> run_key(n_runs);
+    std::vector<unsigned int> run_key32(narrow ? n_runs : 0);
     CCAL_HIP(ctx, hipMemcpyAsync(all.data(), cent.p, all.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-    CCAL_HIP(ctx, hipMemcpyAsync(run_key.data(), uniq.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost, st));
+    if (narrow) CCAL_HIP(ctx, hipMemcpyAsync(run_key32.data(), uniq.p, (size_t)n_runs * 4, hipMemcpyDeviceToHost, st));
+    else CCAL_HIP(ctx, hipMemcpyAsync(run_key.data(), uniq.p, (size_t)n_runs * 8, hipMemcpyDeviceToHost, st));
     CCAL_HIP(ctx, hipStreamSynchronize(st));
+    if (narrow) std::copy(run_key32.begin(), run_key32.end(), run_key.begin());
     std::vector<float> down;
     down.reserve(all.size());
     std::vector<size_t> sizes(C, 0);
