@@ -1473,8 +1473,8 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
 //                the 32 (+2 chained) FP32 accumulation steps inside the matrix pipe are budgeted
 //                at one ulp (2u) each, truncation included, and the dropped low*low term at u.
 //                All on magnitudes <= rn |p - c| + w4.
-//   accumulation:   128 FP32 adds per lane partial + 4 in the promotion, of non-negative terms:
-//                relative 132u of the sum; one more u for the float the cost is stored as.
+//   accumulation:   4 kFlushGroups = 256 FP32 adds per lane partial + 4 in the promotion, of non-negative
+//                terms: relative 260u of the sum; one more u for the float the cost is stored as.
 //   separable pass: w, p - c, the rotation constant a and the translation constant b rounded to float,
 //                an FP32 chain of three fused steps (budgeted as four roundings) on magnitudes <= rn |p - c| + |a|, fixed point
 //                (truncation: below one unit; the sign taken from the unrounded value: one more; budgeted as three):
@@ -1545,7 +1545,7 @@ static GridBudget grid_budget(const ccal_ctx* ctx, const CloudSet& cs, const dou
         total += budget;
     }
     gb.abs_err = std::isfinite(total) ? kScreenSlack * total / (double)C : inf;
-    gb.rel_err = separable ? 2.0 * u24 : kScreenSlack * 133.0 * u24;
+    gb.rel_err = separable ? 2.0 * u24 : kScreenSlack * (4.0 * kFlushGroups + 5.0) * u24;
     return gb;
 }
 

@@ -45,7 +45,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // coalesced dword per lane is the A operand of a 16-candidate tile.
 constexpr int kGroupPoints = 64;
 constexpr int kTilePoints = 16;
-constexpr int kFlushGroups = 32;  // FP32 partial sums are promoted every 128 adds
+constexpr int kFlushGroups = 64;  // FP32 partial sums are promoted every 256 adds
 
 // ---------------------------------------------------------------------------
 // Upload: device-side re-tiling
