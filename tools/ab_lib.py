@@ -10,6 +10,7 @@ from cameracalibration_amd.synthetic import make_scene
 s = make_scene(20, 300000)
 opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
+opt.set_search_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 g = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / 9] * 3 + [10.0 / 9] * 3, [10] * 6)
 for rep in range(4):
     idx, cost, pose, st = opt.grid_search(s.pose_init, g)
