@@ -1575,12 +1575,22 @@ struct DistanceSource {
     // the whole run through the plain division.
     __device__ inline bool values(const Raw& r, double d[kChainRun]) const
     {
-        constexpr unsigned kLo = 0x1a700000u, kHi = 0x65700000u;   // high words of 2^-600, 2^600
         double a[kChainRun];
+        numerators(r, a);
+        return quotients(a, d);
+    }
+    // The two halves of values(): |a qx + b qy + c qz + d| of the run, and its division by the norm.
+    __device__ inline void numerators(const Raw& r, double a[kChainRun]) const
+    {
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) a[t] = exact_numerator(M, pl, r.x[t], r.y[t], r.z[t]);
+    }
+    __device__ inline bool quotients(const double a[kChainRun], double d[kChainRun]) const
+    {
+        constexpr unsigned kLo = 0x1a700000u, kHi = 0x65700000u;   // high words of 2^-600, 2^600
         unsigned hmin = 0xffffffffu, hmax = 0u;
 #pragma unroll
         for (int t = 0; t < kChainRun; ++t) {
-            a[t] = exact_numerator(M, pl, r.x[t], r.y[t], r.z[t]);
             const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(a[t]) >> 32);
             hmin = hi < hmin ? hi : hmin;
             hmax = hi > hmax ? hi : hmax;
@@ -1696,6 +1706,35 @@ __device__ inline void chain_fold_run(const double d[kChainRun], double scale, u
             inc1 += n + ((is_tie && ((inc1 + 1ull) & 1ull)) ? sgn : 0ull);
         }
     }
+}
+
+// The same map from the numerators, without dividing, for the runs in which that is certain to agree.
+// The reference's element is d = RN(a / b) (src/camera_calibration_optimization.cpp:121-129) and the fold
+// wants n = RN-even(d * scale).  With y = RN(1/b) and ys = y * scale (exact: scale is a power of two and the
+// caller has checked that ys is an ordinary number), t = RN(a * ys) lies within 3 * 2^-53 * t of d * scale
+// (one rounding in d, one in y, one in t), so whenever t is farther than thr = 2^-51 * t (+ 2^-60 for
+// results in the subnormal range) from every half-integer, d * scale and t round to the same integer and
+// d * scale is not a tie.  The distance of t from the half-integers is 1/2 - |t - n|, which the fold
+// computes anyway.  half_lo = 1/2 - thr for the run's largest element (the caller has checked that it is
+// below 2^51); `unsure` comes back true if an element is closer than that, is not a number or is infinite
+// -- such runs are divided and folded by chain_fold_run.  Six instructions per element fewer (the
+// division's five, the range test and the scaling give way to one product).
+__device__ inline void chain_fold_run_quick(const double a[kChainRun], double ys, double half_lo,
+                                            unsigned long long& inc, bool& unsure)
+{
+    const double two52 = 4503599627370496.0;
+    constexpr unsigned long long kBits52 = 0x4330000000000000ull;
+    unsigned long long sum = 0;
+    unsure = false;
+#pragma unroll
+    for (int t = 0; t < kChainRun; ++t) {
+        const double tt = a[t] * ys;
+        const double tm = tt + two52;
+        sum += (unsigned long long)__double_as_longlong(tm);
+        const double diff = tt - (tm - two52);
+        unsure = unsure || !(__builtin_fabs(diff) < half_lo);     // written so that a NaN is unsure
+    }
+    inc = sum - (unsigned long long)kChainRun * kBits52;
 }
 
 // Sum (ordered, continuing from s0) and, if kWantMax, maximum (:306-307, order-free) of elements
@@ -1992,21 +2031,11 @@ __global__ __launch_bounds__(64 * kSplitWaves, 4) void split_chain_kernel(
     DistanceSource::Raw raw = src.fetch(b0 + (int64_t)(s_begin + wave) * kChainSeg + lane * kChainRun);
     for (int seg = s_begin + wave; seg < s_end; seg += kSplitWaves) {
         const int64_t g0 = b0 + (int64_t)seg * kChainSeg + lane * kChainRun;
-        double d[kChainRun];
-        bool finite = src.values(raw, d);
+        double a[kChainRun];
+        src.numerators(raw, a);
         // the next segment's coordinates are in flight while this one is folded
         if (seg + kSplitWaves < s_end) raw = src.fetch(g0 + (int64_t)kSplitWaves * kChainSeg);
-        if (g0 + kChainRun > e) {                     // the chain's last run(s): elements past the end count as +0.0
-            finite = true;
-#pragma unroll
-            for (int t = 0; t < kChainRun; ++t) {
-                d[t] = g0 + t < e ? d[t] : 0.0;
-                finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
-            }
-        }
-        double run_max = d[0];
-#pragma unroll
-        for (int t = 1; t < kChainRun; ++t) run_max = max_f64(run_max, d[t]);
+        const bool past_end = g0 + kChainRun > e;     // the chain's last run(s): elements past the end count as +0.0
 
         // the previous evaluation's sums at this segment's ends, widened by 1/64 either way
         const double lo = ref[seg] * (1.0 - 0.015625), hi = ref[seg + 1] * (1.0 + 0.015625);
@@ -2014,33 +2043,87 @@ __global__ __launch_bounds__(64 * kSplitWaves, 4) void split_chain_kernel(
         const int eb_hi = (int)((unsigned long long)__double_as_longlong(hi) >> 52);
         const bool guess = eb_lo >= 64 && eb_lo <= 1999;      // sign bit set or out of range: no map
         const bool dual = guess && eb_hi != eb_lo;
+        const double scale_a = __longlong_as_double((long long)((unsigned long long)(2098 - (guess ? eb_lo : 1023)) << 52));
+        const double scale_b = scale_a * 0.5;
         unsigned long long a0 = 0, a1 = 0, c0 = 0, c1 = 0;
         bool ok_a = false, ok_b = false;
+
+        // First without dividing (chain_fold_run_quick): needs the reciprocal of the norm (pl[6]), the
+        // run's largest element below 2^51 units and every element clear of the rounding boundaries.
+        bool quick = guess;
         if (guess) {
-            const double scale = __longlong_as_double((long long)((unsigned long long)(2098 - eb_lo) << 52));
-            bool tie = false;
-            bool ok = finite && run_max * scale < two52;
-            if (ok) chain_fold_run(d, scale, a0, a1, tie);
-            if (__any(tie ? 1 : 0)) {
-                chain_compose_wave(a0, a1);
-            } else {
-                for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
-                a1 = a0;
+            // reciprocal of the norm in units of the finer guess; its scaling must not leave the normal range
+            const double ys = src.pl[5] * scale_a;
+            bool unsure = !(src.pl[6] != 0.0 && ys > 0x1p-1000 && ys < 0x1p1000);
+            if (!unsure) {
+                if (past_end) {
+#pragma unroll
+                    for (int t = 0; t < kChainRun; ++t) a[t] = g0 + t < e ? a[t] : 0.0;
+                }
+                double amax = a[0];
+#pragma unroll
+                for (int t = 1; t < kChainRun; ++t) amax = max_f64(amax, a[t]);
+                const double tmax = amax * ys;
+                unsure = !(tmax < 2251799813685248.0);                     // 2^51; a NaN is unsure
+                const double thr = tmax * 0x1p-51 + 0x1p-60;
+                bool u1 = false, u2 = false;
+                chain_fold_run_quick(a, ys, 0.5 - thr, a0, u1);
+                // the coarser unit: half the values, half the distance (the subnormal allowance stays)
+                if (dual) chain_fold_run_quick(a, ys * 0.5, 0.5 - (tmax * 0x1p-52 + 0x1p-60), c0, u2);
+                unsure = unsure || u1 || u2;
             }
-            ok_a = __all(ok ? 1 : 0);
+            quick = !__any(unsure ? 1 : 0);
         }
-        if (dual) {
-            const double scale = __longlong_as_double((long long)((unsigned long long)(2097 - eb_lo) << 52));
-            bool tie = false;
-            bool ok = finite && run_max * scale < two52;
-            if (ok) chain_fold_run(d, scale, c0, c1, tie);
-            if (__any(tie ? 1 : 0)) {
-                chain_compose_wave(c0, c1);
-            } else {
+        if (quick) {
+            for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
+            a1 = a0;
+            ok_a = true;
+            if (dual) {
                 for (int off = 32; off > 0; off >>= 1) c0 += __shfl_xor(c0, off, 64);
                 c1 = c0;
+                ok_b = true;
             }
-            ok_b = __all(ok ? 1 : 0);
+        } else if (guess) {
+            // the reference's own division, then the general fold
+            double d[kChainRun];
+            bool finite = src.quotients(a, d);
+            if (past_end) {
+                finite = true;
+#pragma unroll
+                for (int t = 0; t < kChainRun; ++t) {
+                    d[t] = g0 + t < e ? d[t] : 0.0;
+                    finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+                }
+            }
+            double run_max = d[0];
+#pragma unroll
+            for (int t = 1; t < kChainRun; ++t) run_max = max_f64(run_max, d[t]);
+            {
+                bool tie = false;
+                bool ok = finite && run_max * scale_a < two52;
+                a0 = 0; a1 = 0;
+                if (ok) chain_fold_run(d, scale_a, a0, a1, tie);
+                if (__any(tie ? 1 : 0)) {
+                    chain_compose_wave(a0, a1);
+                } else {
+                    for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
+                    a1 = a0;
+                }
+                ok_a = __all(ok ? 1 : 0);
+            }
+            c0 = 0; c1 = 0;
+            if (dual) {
+                bool tie = false;
+                bool ok = finite && run_max * scale_b < two52;
+                if (ok) chain_fold_run(d, scale_b, c0, c1, tie);
+                if (__any(tie ? 1 : 0)) {
+                    chain_compose_wave(c0, c1);
+                } else {
+                    for (int off = 32; off > 0; off >>= 1) c0 += __shfl_xor(c0, off, 64);
+                    c1 = c0;
+                }
+                ok_b = __all(ok ? 1 : 0);
+            }
         }
         if (lane == 0) {
             SegMap m;
