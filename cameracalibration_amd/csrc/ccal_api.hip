@@ -987,7 +987,8 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 //   fast path:   w and p - c rounded to float (one rounding each), then three fused multiply-adds (the
 //                innermost product is by exactly 1 and does not round), each on a magnitude of at most
 //                |w123||p - c| + |w4|:  5 * 2^-24 (|w123| rho + |w4|)
-//   sums:        16 + 6 FP32 adds per partial:  22 * 2^-24 of the cloud's mean residual
+//   sums:        4 + 6 FP32 adds per partial (four points per lane, six levels of the wave reduction):
+//                10 * 2^-24 of the cloud's mean residual
 // The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
 constexpr double kScreenSlack = 1.25;
 
@@ -1009,7 +1010,7 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
         const int nb = std::min(max_batch, n_poses - k0);
         CCAL_HIP(ctx, ctx->screen_in.ensure((size_t)nb * C * 4 * sizeof(float)));
         CCAL_HIP(ctx, ctx->screen_out.ensure((size_t)nb * C * sizeof(double)));
-        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * nb * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * kScreenQuarters * nb * sizeof(double)));
         float* w = ctx->screen_in.as<float>();
         double* sums = ctx->screen_out.as<double>();
         std::vector<double> budget((size_t)nb * C);
@@ -1048,7 +1049,7 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->screen_w.p, w, (size_t)nb * C * 4 * sizeof(float), hipMemcpyHostToDevice,
                                      ctx->stream));
         if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
-        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
+        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks * kScreenQuarters), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
                            cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
                            ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
         hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 3) / 4), dim3(256), 0, ctx->stream,
@@ -1069,7 +1070,7 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
             for (int j = 0; j < C; ++j) {
                 const double mean = sums[(size_t)k * C + j] / (double)cs.n_pts[j];
                 f += mean;
-                b += budget[(size_t)k * C + j] + 22.0 * u24 * mean;
+                b += budget[(size_t)k * C + j] + 10.0 * u24 * mean;
             }
             cost[k0 + k] = f / (double)C;
             bound[k0 + k] = std::isfinite(b) ? kScreenSlack * b / (double)C : std::numeric_limits<double>::infinity();

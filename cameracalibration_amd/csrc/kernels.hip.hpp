@@ -1290,17 +1290,18 @@ __global__ __launch_bounds__(256) void separable_reduce_kernel(const double* __r
 // Screening pass: the folded FP32 objective of a few poses, one pass over the points
 // ---------------------------------------------------------------------------
 // sum_i |w.(p_i - c, 1)| per (pose, cloud) for up to a few dozen poses at once: every lane keeps
-// 16 points in registers and walks the poses in tiles of kScreenTile (the four-vectors are uniform:
+// 4 points in registers and walks the poses in tiles of kScreenTile (the four-vectors are uniform:
 // scalar loads).  Roundings per residual: four (three fused multiply-adds and a product); per
-// partial sum: 16 FP32 adds in the lane and 6 in the wave reduction; everything after that is
+// partial sum: 4 FP32 adds in the lane and 6 in the wave reduction; everything after that is
 // FP64 in a fixed order.  The caller turns these counts into an error bound.
 struct BlockDesc;
 constexpr int kScreenTile = 16;
+constexpr int kScreenQuarters = 4;      // workgroups per block of the table, see screen_cost_kernel
 
 __global__ __launch_bounds__(256) void screen_cost_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
     const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w /* [pose][cloud] */, int n_poses,
-    int n_clouds, double* __restrict__ partial /* [block][pose] */);
+    int n_clouds, double* __restrict__ partial /* [block * kScreenQuarters + quarter][pose] */);
 
 // out[pose * n_clouds + cloud] = sum of the cloud's block partials; one wave per (pose, cloud): lane l adds
 // the partials l, l + 64, ... in order, then the lanes combine in a fixed tree (the same bits on every run).
@@ -1313,7 +1314,8 @@ __global__ __launch_bounds__(256) void screen_reduce_kernel(const double* __rest
     if (i >= n_poses * n_clouds) return;
     const int p = i / n_clouds, j = i % n_clouds;
     double s = 0.0;
-    for (int b = cloud_block_off[j] + lane; b < cloud_block_off[j + 1]; b += 64) s += partial[(int64_t)b * n_poses + p];
+    for (int b = kScreenQuarters * cloud_block_off[j] + lane; b < kScreenQuarters * cloud_block_off[j + 1]; b += 64)
+        s += partial[(int64_t)b * n_poses + p];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) out[i] = s;
 }
@@ -1329,35 +1331,80 @@ struct BlockDesc {
     int64_t end;
 };
 
+// Totals over the 64 lanes of a wave of 16 values per lane at once: the 16 lanes of a row reduce-scatter
+// (four exchange steps: a lane keeps one half of its values and adds the partner's copy of that half), then
+// the four rows are added; lane l returns the total of value l & 15.  Six FP32 adds per total, as a
+// butterfly per value would take, for a third of the instructions.
+__device__ inline float wave_sum16(const float (&v)[16], int lane)
+{
+    const int col = lane & 15;
+    float w8[8], w4[4], w2[2];
+    {
+        const bool hi = (col & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float keep = hi ? v[8 + i] : v[i], give = hi ? v[i] : v[8 + i];
+            w8[i] = keep + __shfl_xor(give, 8, 64);
+        }
+    }
+    {
+        const bool hi = (col & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = hi ? w8[4 + i] : w8[i], give = hi ? w8[i] : w8[4 + i];
+            w4[i] = keep + __shfl_xor(give, 4, 64);
+        }
+    }
+    {
+        const bool hi = (col & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = hi ? w4[2 + i] : w4[i], give = hi ? w4[i] : w4[2 + i];
+            w2[i] = keep + __shfl_xor(give, 2, 64);
+        }
+    }
+    const bool hi = (col & 1) != 0;
+    float r = (hi ? w2[1] : w2[0]) + __shfl_xor(hi ? w2[0] : w2[1], 1, 64);
+    r += __shfl_xor(r, 16, 64);
+    r += __shfl_xor(r, 32, 64);
+    return r;
+}
+
+// A workgroup takes a quarter of a block of the table (kScreenQuarters per block: 1024 points, four per
+// lane): with whole blocks the benchmark's 1465 workgroups were one and a half rounds of what the chip holds
+// at once, and every round began with all of them waiting for their loads.
+
 __global__ __launch_bounds__(256) void screen_cost_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
     const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w, int n_poses, int n_clouds,
-    double* __restrict__ partial)
+    double* __restrict__ partial /* [block * kScreenQuarters + quarter][pose] */)
 {
     __shared__ float red[4][kScreenTile];
-    const BlockDesc bd = blocks[blockIdx.x];
+    const BlockDesc bd = blocks[blockIdx.x / kScreenQuarters];
+    const int quarter = blockIdx.x % kScreenQuarters;
     const int j = bd.cloud;
     // a block of the table is 4096 consecutive points of one cloud = 64 groups
     const int64_t lb = bd.begin - cloud_pt_off[j], le = bd.end - cloud_pt_off[j];
-    const int g0 = group_off[j] + (int)(lb / kGroupPoints);
+    const int g0 = group_off[j] + (int)(lb / kGroupPoints) + quarter * 16;
     const int g1 = group_off[j] + (int)((le + kGroupPoints - 1) / kGroupPoints);
+    double* out = partial + (int64_t)blockIdx.x * n_poses;
+    if (g0 >= g1) {                                   // a short last block: nothing in this quarter
+        for (int p = threadIdx.x; p < n_poses; p += 256) out[p] = 0.0;
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, gsel = lane >> 4;
     // The fourth row of a group (1 for a point, 0 for padding) is not loaded: it follows from the point's index.
     const int64_t n_j = cloud_pt_off[j + 1] - cloud_pt_off[j];
-    f32x4 X[4], Y[4], Z[4], O[4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 X = zero, Y = zero, Z = zero, O = zero;      // absent groups add |0|
+    const int g = g0 + wave * 4 + gsel;
+    if (g < g1) {
+        const f32x4* gp = groups + (int64_t)g * 64 + col;
+        X = gp[0]; Y = gp[16]; Z = gp[32];
+        const int64_t first = (int64_t)(g - group_off[j]) * kGroupPoints + col;
 #pragma unroll
-    for (int trip = 0; trip < 4; ++trip) {
-        const int g = g0 + trip * 16 + wave * 4 + gsel;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        X[trip] = Y[trip] = Z[trip] = O[trip] = zero;   // absent groups add |0|
-        if (g < g1) {
-            const f32x4* gp = groups + (int64_t)g * 64 + col;
-            X[trip] = gp[0]; Y[trip] = gp[16]; Z[trip] = gp[32];
-            const int64_t first = (int64_t)(g - group_off[j]) * kGroupPoints + col;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) O[trip][u] = first + u * kTilePoints < n_j ? 1.f : 0.f;
-        }
+        for (int u = 0; u < 4; ++u) O[u] = first + u * kTilePoints < n_j ? 1.f : 0.f;
     }
     for (int p0 = 0; p0 < n_poses; p0 += kScreenTile) {
         float acc[kScreenTile];
@@ -1370,29 +1417,22 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
             const f32x2 w0 = {wv[0], wv[0]}, w1 = {wv[1], wv[1]}, w2 = {wv[2], wv[2]}, w3 = {wv[3], wv[3]};
             float a = 0.f;
 #pragma unroll
-            for (int trip = 0; trip < 4; ++trip)
-#pragma unroll
-                for (int h = 0; h < 4; h += 2) {
-                    const f32x2 x = {X[trip][h], X[trip][h + 1]}, y = {Y[trip][h], Y[trip][h + 1]};
-                    const f32x2 z = {Z[trip][h], Z[trip][h + 1]}, o = {O[trip][h], O[trip][h + 1]};
-                    const f32x2 r = __builtin_elementwise_fma(w0, x, __builtin_elementwise_fma(w1, y,
-                                    __builtin_elementwise_fma(w2, z, w3 * o)));
-                    a += __builtin_fabsf(r[0]);
-                    a += __builtin_fabsf(r[1]);
-                }
+            for (int h = 0; h < 4; h += 2) {
+                const f32x2 x = {X[h], X[h + 1]}, y = {Y[h], Y[h + 1]};
+                const f32x2 z = {Z[h], Z[h + 1]}, o = {O[h], O[h + 1]};
+                const f32x2 r = __builtin_elementwise_fma(w0, x, __builtin_elementwise_fma(w1, y,
+                                __builtin_elementwise_fma(w2, z, w3 * o)));
+                a += __builtin_fabsf(r[0]);
+                a += __builtin_fabsf(r[1]);
+            }
             acc[t] = a;
         }
-#pragma unroll
-        for (int t = 0; t < kScreenTile; ++t) {
-            float a = acc[t];
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-            if (lane == 0) red[wave][t] = a;
-        }
+        const float tot = wave_sum16(acc, lane);
+        if (lane < kScreenTile) red[wave][lane] = tot;
         __syncthreads();
         if (threadIdx.x < kScreenTile && p0 + (int)threadIdx.x < n_poses) {
             const int t = threadIdx.x;
-            partial[(int64_t)blockIdx.x * n_poses + p0 + t] =
-                (((double)red[0][t] + (double)red[1][t]) + (double)red[2][t]) + (double)red[3][t];
+            out[p0 + t] = (((double)red[0][t] + (double)red[1][t]) + (double)red[2][t]) + (double)red[3][t];
         }
         __syncthreads();
     }
