@@ -2024,8 +2024,10 @@ __device__ __host__ inline int split_part_segments(int n_seg, int K)
     return (per + kSplitWaves - 1) / kSplitWaves * kSplitWaves;
 }
 
-// Four waves per SIMD: with five (96 registers) the loop spills 67 of them to scratch and runs 8 % slower.
-__global__ __launch_bounds__(64 * kSplitWaves, 4) void split_chain_kernel(
+// Five waves per SIMD (96 registers, one spilled): since the parts fold without dividing the loop fits, and the
+// fifth wave is worth 1.2 % (with the division in the loop it spilled 67 registers at five waves and ran 8 %
+// slower than at four); six waves spill 127.
+__global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
     const int64_t* __restrict__ cloud_pt_off, const int64_t* __restrict__ cloud_seg_off,
     const double* __restrict__ mats, const double* __restrict__ planes, int n_poses, int n_clouds,
@@ -2073,7 +2075,12 @@ __global__ __launch_bounds__(64 * kSplitWaves, 4) void split_chain_kernel(
         const int64_t g0 = b0 + (int64_t)seg * kChainSeg + lane * kChainRun;
         double a[kChainRun];
         src.numerators(raw, a);
-        // the next segment's coordinates are in flight while this one is folded
+        // The next segment's coordinates are in flight while this one is folded.  The numerators must be
+        // complete before the loads are issued (the empty statement pins them here): computed after the
+        // loads they would read a copy of the coordinates, a second set of 24 registers filled and emptied
+        // by 48 moves per trip -- a tenth of the loop's instructions (if not of its time: 0.2 %).
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+        static_assert(kChainRun == 8, "the statement above names every numerator of a run");
         if (seg + kSplitWaves < s_end) raw = src.fetch(g0 + (int64_t)kSplitWaves * kChainSeg);
         const bool past_end = g0 + kChainRun > e;     // the chain's last run(s): elements past the end count as +0.0
 

@@ -11,6 +11,8 @@ s = make_scene(nc, npts)
 opt = cc.Optimizer(0)
 opt.upload_clouds(0, s.clouds, s.base_T_flange); opt.set_plane(s.plane)
 o = cc.GdOptions.default()
+if os.environ.get("PROBE_MAXIT"):
+    o.max_iterations = int(os.environ["PROBE_MAXIT"])
 if os.environ.get('PROBE_NOSPLIT'):
     opt.set_chain_split(False)
 if os.environ.get('PROBE_NOSCREEN'):

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r2
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-candidates 0"
-SHORT="python3 bench.py --steps 1 --warmup 1 --cpu-candidates 0 --gd-iterations 40 --f32-steps 1"
+SHORT="python3 bench.py --steps 1 --warmup 1 --cpu-candidates 0 --f32-steps 1"
 echo "[profile] kernel trace"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
 pass() {   # tag, program..., then "--", counters...
