@@ -1681,17 +1681,65 @@ __device__ inline void chain_compose(unsigned long long& a0, unsigned long long&
     a1 = n1;
 }
 
-// Inclusive prefix composition over the first N lanes of a wave (lower lane first).
-template <int N>
-__device__ inline void chain_scan(unsigned long long& i0, unsigned long long& i1, int lane)
+// A 64-bit value moved between lanes by the data-parallel-primitive path of the vector unit (no LDS round
+// trip, which is what a ds_bpermute shuffle costs a lone wave: ~100 cycles each).  Lanes without a source
+// (the first lanes of a row for a row shift, the rows the mask leaves out) receive 0.  Every lane of the wave
+// must be active.
+template <int kCtrl, int kRowMask>
+__device__ inline unsigned long long dpp_move_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int off = 1; off < N; off <<= 1) {
-        unsigned long long l0 = __shfl_up(i0, off, 64);
-        unsigned long long l1 = __shfl_up(i1, off, 64);
-        chain_compose(l0, l1, i0, i1);
-        if (lane >= off) { i0 = l0; i1 = l1; }
-    }
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, kCtrl, kRowMask, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), kCtrl, kRowMask, 0xf, true);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+constexpr int kDppRowShr = 0x110;        // + n: lane l of a row of 16 reads lane l - n of the same row
+constexpr int kDppRowBcast15 = 0x142;    // every lane of a row reads lane 15 of the row before
+constexpr int kDppRowBcast31 = 0x143;    // rows 2 and 3 read lane 31
+constexpr int kDppWaveShr1 = 0x138;      // lane l reads lane l - 1 of the wave
+
+// v of lane `from`, the same lane for the whole wave (a scalar register index: v_readlane, no LDS).
+__device__ inline unsigned long long read_lane_u64(unsigned long long v, int from)
+{
+    const int f = __builtin_amdgcn_readfirstlane(from);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, f);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), f);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Inclusive prefix composition over the first N lanes of a wave (lower lane first): shifts by 1, 2, 4, 8
+// inside the rows of 16, then the row totals are carried into the rows behind them.  The map (0, 0) a lane
+// without a source receives is the identity of the composition, so no lane needs to be excluded.
+template <int kCtrl, int kRowMask>
+__device__ inline void chain_scan_step(unsigned long long& i0, unsigned long long& i1)
+{
+    unsigned long long l0 = dpp_move_u64<kCtrl, kRowMask>(i0), l1 = dpp_move_u64<kCtrl, kRowMask>(i1);
+    chain_compose(l0, l1, i0, i1);
+    i0 = l0;
+    i1 = l1;
+}
+
+// Sum of v over the 64 lanes of a wave (every lane active), the same value returned to all of them: prefix
+// sums by the same six moves, the total read back from lane 63.
+__device__ inline unsigned long long wave_sum_u64(unsigned long long v)
+{
+    v += dpp_move_u64<kDppRowShr + 1, 0xf>(v);
+    v += dpp_move_u64<kDppRowShr + 2, 0xf>(v);
+    v += dpp_move_u64<kDppRowShr + 4, 0xf>(v);
+    v += dpp_move_u64<kDppRowShr + 8, 0xf>(v);
+    v += dpp_move_u64<kDppRowBcast15, 0xa>(v);
+    v += dpp_move_u64<kDppRowBcast31, 0xc>(v);
+    return read_lane_u64(v, 63);
+}
+
+template <int N>
+__device__ inline void chain_scan(unsigned long long& i0, unsigned long long& i1, int /*lane*/)
+{
+    if (N > 1) chain_scan_step<kDppRowShr + 1, 0xf>(i0, i1);
+    if (N > 2) chain_scan_step<kDppRowShr + 2, 0xf>(i0, i1);
+    if (N > 4) chain_scan_step<kDppRowShr + 4, 0xf>(i0, i1);
+    if (N > 8) chain_scan_step<kDppRowShr + 8, 0xf>(i0, i1);
+    if (N > 16) chain_scan_step<kDppRowBcast15, 0xa>(i0, i1);
+    if (N > 32) chain_scan_step<kDppRowBcast31, 0xc>(i0, i1);
 }
 
 // Composition of the 64 lane maps of a wave in lane order; valid in lane 0.
@@ -1872,8 +1920,16 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
                 if (!wave_tie) {
                     // no ties in the segment: both parities add the plain sum of the lane totals,
                     // formed by the LDS adder (a wave's LDS operations execute in order)
-                    if (lane == 0) sh_inc[wave][0] = 0ull;
-                    atomicAdd(&sh_inc[wave][0], inc0);
+                    if (W == 1) {
+                        // a lone wave (the finishing pass) waits for every LDS round trip: sum in registers
+                        const unsigned long long tot = wave_sum_u64(inc0);
+                        if (lane == 0) sh_inc[wave][0] = tot;
+                    } else {
+                        // several waves per SIMD hide the round trip, and the LDS adder is one instruction
+                        // (measured with the register sum here too: whole chains 1.7 % slower)
+                        if (lane == 0) sh_inc[wave][0] = 0ull;
+                        atomicAdd(&sh_inc[wave][0], inc0);
+                    }
                 } else {
                     unsigned long long t0 = inc0, t1 = inc1;
                     chain_compose_wave(t0, t1);
@@ -1906,7 +1962,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
                 const bool bad = lane < nseg && (!seg_ok || S + tot >= kTwo53);
                 const unsigned long long mask = __ballot(bad ? 1 : 0);
                 const int adv = mask ? __builtin_ctzll(mask) : nseg;
-                const unsigned long long before = __shfl(tot, adv > 0 ? adv - 1 : 0, 64);
+                const unsigned long long before = read_lane_u64(tot, adv > 0 ? adv - 1 : 0);
                 if (lane == 0) {
                     sh_S = adv > 0 ? S + before : S;
                     sh_adv = adv;
@@ -1926,7 +1982,7 @@ __device__ inline void chain_reduce(const Source& src, int64_t b, int64_t e, dou
                 const bool bad = !ok || Sx + tot >= kTwo53;
                 const unsigned long long mask = __ballot(bad ? 1 : 0);
                 const int L = mask ? __builtin_ctzll(mask) : 63;             // mask is never empty here
-                const unsigned long long before = __shfl(tot, L > 0 ? L - 1 : 0, 64);
+                const unsigned long long before = read_lane_u64(tot, L > 0 ? L - 1 : 0);
                 if (lane == L) {
                     double sv = from_units(L > 0 ? Sx + before : Sx);
 #pragma unroll
@@ -2122,11 +2178,11 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
             quick = !__any(unsure ? 1 : 0);
         }
         if (quick) {
-            for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
+            a0 = wave_sum_u64(a0);
             a1 = a0;
             ok_a = true;
             if (dual) {
-                for (int off = 32; off > 0; off >>= 1) c0 += __shfl_xor(c0, off, 64);
+                c0 = wave_sum_u64(c0);
                 c1 = c0;
                 ok_b = true;
             }
@@ -2153,7 +2209,7 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
                 if (__any(tie ? 1 : 0)) {
                     chain_compose_wave(a0, a1);
                 } else {
-                    for (int off = 32; off > 0; off >>= 1) a0 += __shfl_xor(a0, off, 64);
+                    a0 = wave_sum_u64(a0);
                     a1 = a0;
                 }
                 ok_a = __all(ok ? 1 : 0);
@@ -2166,7 +2222,7 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
                 if (__any(tie ? 1 : 0)) {
                     chain_compose_wave(c0, c1);
                 } else {
-                    for (int off = 32; off > 0; off >>= 1) c0 += __shfl_xor(c0, off, 64);
+                    c0 = wave_sum_u64(c0);
                     c1 = c0;
                 }
                 ok_b = __all(ok ? 1 : 0);
@@ -2246,13 +2302,13 @@ __global__ __launch_bounds__(64) void split_finish_kernel(
             const bool bad = lane >= cur && lane < nl && (!valid || !usable || S + tot >= kTwo53);
             const unsigned long long mask = __ballot(bad ? 1 : 0);
             const int adv = mask ? __builtin_ctzll(mask) : nl;          // first segment that cannot be applied
-            const unsigned long long prev = __shfl_up(tot, 1, 64);
+            const unsigned long long prev = dpp_move_u64<kDppWaveShr1, 0xf>(tot);
             if (ref && lane >= cur && lane < adv) {
                 const unsigned long long at = lane > cur ? S + prev : S;
                 ref[base + lane] = __longlong_as_double((long long)((at & kMantissa) | ((unsigned long long)eb << 52)));
             }
             if (adv > cur) {
-                const unsigned long long before = __shfl(tot, adv - 1, 64);
+                const unsigned long long before = read_lane_u64(tot, adv - 1);
                 s = __longlong_as_double((long long)(((S + before) & kMantissa) | ((unsigned long long)eb << 52)));
             }
             if (adv < nl) {
