@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence of this round: one kernel-trace/stats run of the benchmark and
+# Collects the rocprofv3 evidence kept under profiles/: one kernel-trace/stats run of the benchmark and
 # PMC passes (each counter group in a run of its own, never together with a trace option) for the
 # residual kernel, the separable histogram kernel, the exact path's part kernel and the moment
 # kernel.  Run through gpurun from the repo root; summaries are written by tools/summarize_pmc.py.
