@@ -774,6 +774,44 @@ def test_gradient_descent_chain_split_changes_nothing(gpu_opt, oracle):
             assert (ref.iterations, ref.n_evals, ref.fval) == (w.iterations, w.n_evals, w.fval)
 
 
+def test_chain_split_with_every_element_on_a_rounding_boundary(gpu_opt, oracle):
+    """Identity robot poses, plane z = 0 with a unit normal and a zero pose: a point's distance is |z| exactly.
+    One leading point lifts the running sum into a binade whose unit is twice the grid the other points'
+    |z| lie on, with odd multiples: every later add is an exact tie (round half to even), and the lifts of the
+    other clouds put their sums one unit off a tie or into the binade where every add is exact.  The parts that
+    fold without dividing must recognise that they cannot decide such runs; whole chains, split chains with the
+    previous evaluation's sums as guesses, and split chains after a jump of the pose all give the oracle's bits."""
+    rng = np.random.default_rng(12)
+    clouds = []
+    for n, lift in ((40000, 3.0 * 2.0 ** 40), (70001, 2.0 ** 40), (33000, 3.0 * 2.0 ** 41 + 2.0 ** 20)):
+        z = (2 * rng.integers(0, 2048, n) + 1).astype(np.float64) * 2.0 ** -12
+        z[0] = lift
+        z[1::7] *= -1.0                                   # either side of the plane: the distance is |z|
+        c = np.column_stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), z]).astype(np.float32)
+        assert np.all(c[:, 2].astype(np.float64) == z)
+        clouds.append(np.ascontiguousarray(c))
+    B = np.repeat(np.eye(4).reshape(1, 16), len(clouds), axis=0)
+    plane = np.float32([0, 0, 1, 0])
+    o = oracle.OracleScene(clouds, B)
+    zero = np.zeros(6)
+    shifted = np.array([0.0, 0.0, 2.0 ** -12, 0.0, 0.0, 0.0])      # one grid step: even multiples, other sums
+    tilted = np.array([1e-3, -2e-3, 5e-4, 1e-4, -2e-4, 3e-4])      # off the grid
+    want = {k: o.get_error(p, plane) for k, p in (("zero", zero), ("shifted", shifted), ("tilted", tilted))}
+    for split in (False, True):
+        gpu_opt.upload_clouds(0, clouds, B)
+        gpu_opt.set_plane(plane)
+        gpu_opt.set_chain_split(split)
+        try:
+            for _ in range(3):                            # the first call runs whole chains and leaves the sums behind
+                assert gpu_opt.get_error(zero[None, :])[0] == want["zero"]
+            got = gpu_opt.get_error(np.stack([zero, shifted, zero, tilted, shifted]))
+            assert list(got) == [want["zero"], want["shifted"], want["zero"], want["tilted"], want["shifted"]]
+            assert gpu_opt.get_error(tilted[None, :])[0] == want["tilted"]
+            assert gpu_opt.get_error(zero[None, :])[0] == want["zero"]
+        finally:
+            gpu_opt.set_chain_split(True)
+
+
 def test_multi_start_gd_equals_single_starts(gpu_opt):
     s = make_scene(3, 400, seed=8)
     upload(gpu_opt, s)
