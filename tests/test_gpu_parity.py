@@ -774,8 +774,11 @@ def test_gradient_descent_chain_split_changes_nothing(gpu_opt, oracle):
             assert (ref.iterations, ref.n_evals, ref.fval) == (w.iterations, w.n_evals, w.fval)
 
 
-def test_chain_split_with_every_element_on_a_rounding_boundary(gpu_opt, oracle):
-    """Identity robot poses, plane z = 0 with a unit normal and a zero pose: a point's distance is |z| exactly.
+@pytest.mark.parametrize("norm", [1.0, 3.0])
+def test_chain_split_with_every_element_on_a_rounding_boundary(gpu_opt, oracle, norm):
+    """Identity robot poses, plane z = 0 and a zero pose: a point's distance is |z| exactly -- also for the
+    normal (0, 0, 3), where the reference's |3 z| / 3 is exactly |z| while a product by the rounded reciprocal
+    of 3 is not: the value the parts fold without dividing then lies beside the tie, not on it.
     One leading point lifts the running sum into a binade whose unit is twice the grid the other points'
     |z| lie on, with odd multiples: every later add is an exact tie (round half to even), and the lifts of the
     other clouds put their sums one unit off a tie or into the binade where every add is exact.  The parts that
@@ -791,7 +794,7 @@ def test_chain_split_with_every_element_on_a_rounding_boundary(gpu_opt, oracle):
         assert np.all(c[:, 2].astype(np.float64) == z)
         clouds.append(np.ascontiguousarray(c))
     B = np.repeat(np.eye(4).reshape(1, 16), len(clouds), axis=0)
-    plane = np.float32([0, 0, 1, 0])
+    plane = np.float32([0, 0, norm, 0])
     o = oracle.OracleScene(clouds, B)
     zero = np.zeros(6)
     shifted = np.array([0.0, 0.0, 2.0 ** -12, 0.0, 0.0, 0.0])      # one grid step: even multiples, other sums
