@@ -791,13 +791,18 @@ __global__ __launch_bounds__(256, 3) void residual_bf16x3_wide_kernel(
     }
 }
 
-// Same contraction, counting |w.p| < thr instead of summing (RANSAC scoring).
-// Padding points have residual 0 and are counted; the host subtracts them.
+// Same contraction, counting instead of summing (RANSAC scoring).  The FP32 residual of a point
+// lies within a known distance e of the reference-arithmetic one (the caller derives e per cloud),
+// so two counts bracket the reference's inlier count of a hypothesis: points with |w.p| < thr - e
+// are inliers for certain, points with |w.p| >= thr + e are not.  thr_tab[cloud] = (thr - e, thr + e),
+// rounded outwards.  partial[0][split][candidate] = certain, partial[1][split][candidate] = possible.
+// Padding points have residual 0 and are counted wherever 0 lies below the bound; the host
+// subtracts them.  Lane counters are 32 bits wide: a lane sees 1/16 of a split's points.
 template <int NA>
 __global__ __launch_bounds__(256) void inlier_mfma_kernel(
     const float* __restrict__ W, const f32x4* __restrict__ groups,
     const int* __restrict__ group_off, unsigned long long* __restrict__ partial,
-    float thr, int n_clouds, int n_ctiles, int n_splits)
+    const f32x2* __restrict__ thr_tab, int n_clouds, int n_ctiles, int n_splits)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -805,12 +810,11 @@ __global__ __launch_bounds__(256) void inlier_mfma_kernel(
     const int split = blockIdx.y;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    unsigned int cnt[NA][4];
-    unsigned long long tot[NA][4];
+    unsigned int lo[NA][4], hi[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { cnt[a][r] = 0; tot[a][r] = 0; }
+        for (int r = 0; r < 4; ++r) { lo[a][r] = 0; hi[a][r] = 0; }
 
     for (int j = 0; j < n_clouds; ++j) {
         const int g0 = group_off[j];
@@ -818,6 +822,8 @@ __global__ __launch_bounds__(256) void inlier_mfma_kernel(
         const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
         const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
         if (gb >= ge) continue;
+        const f32x2 t = thr_tab[j];
+        const float tlo = t[0], thi = t[1];
         float A[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -834,28 +840,32 @@ __global__ __launch_bounds__(256) void inlier_mfma_kernel(
                 for (int a = 0; a < NA; ++a) {
                     f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a], b[u], zero, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cnt[a][r] += (__builtin_fabsf(d[r]) < thr) ? 1u : 0u;
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = __builtin_fabsf(d[r]);
+                        lo[a][r] += (m < tlo) ? 1u : 0u;
+                        hi[a][r] += (m < thi) ? 1u : 0u;
+                    }
                 }
             }
             b = bn;
         }
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { tot[a][r] += cnt[a][r]; cnt[a][r] = 0; }
     }
+    const int64_t plane = (int64_t)n_splits * n_ctiles * 16;
     unsigned long long* out = partial + (int64_t)split * n_ctiles * 16;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            unsigned long long v = tot[a][r];
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
-            v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 8, 64);
-            if ((lane & 15) == 0)
-                out[(int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r] = v;
+            unsigned long long v = lo[a][r], w = hi[a][r];
+            v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
+            v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
+            v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
+            v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
+            if ((lane & 15) == 0) {
+                const int64_t at = (int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r;
+                out[at] = v;
+                out[plane + at] = w;
+            }
         }
 }
 

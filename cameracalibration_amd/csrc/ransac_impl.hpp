@@ -6,9 +6,13 @@
 // the sampling scheme below is this library's own definition:
 //   1. n_hyp three-point hypotheses from a counter-based generator (kernel),
 //   2. every hypothesis scored against every point in ONE pass of the fast
-//      matrix-core contraction (|w.p| < thr counted instead of summed),
-//   3. the leaders of that count re-counted with the reference-arithmetic
-//      distance; most inliers wins, lowest hypothesis index on ties,
+//      matrix-core contraction, counting the points that are inliers for certain
+//      and those that may be (the FP32 residual within a proven error bound of
+//      the threshold),
+//   3. every hypothesis that those two counts cannot exclude re-counted with the
+//      reference-arithmetic distance (strict <); most inliers wins, lowest
+//      hypothesis index on ties -- the winner of a sequential scan in that
+//      arithmetic, whatever the data (points exactly at the threshold included),
 //   4. winner refitted on its inliers: centroid + smallest-eigenvalue
 //      eigenvector of their covariance (what PCL's coefficient optimisation does).
 #pragma once
@@ -87,11 +91,57 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                        cs.cloud_pt_off_dev.as<int64_t>(), C, (int64_t)cs.total_pts,
                        ctx->mats_buf.as<double>(), seed, n_hyp, ctx->rec_buf.as<double>());
 
-    // 2. fast scoring of every (hypothesis, point) pair
+    // 2. fast scoring of every (hypothesis, point) pair, with a bound on what FP32 can misplace.
+    // The reference-arithmetic distance of a point (exact_distance) and its FP32 residual both
+    // approximate r = (n.(M p) + d) / |n|.  Per cloud j, with u = 2^-24, c the cloud's centre,
+    // rho the largest |p - c|, rn >= |R|_2 (R the 3x3 part of M), m = |M (c,1)|, Q = m + rn rho >= |M p|:
+    //   reference:  every coordinate of M p rounded to float, |n_r|/|n| <= 1:           u Q
+    //   fast path:  w and p - c rounded to float, four fused multiply-adds on magnitudes of at
+    //               most |w123| |p - c| + |w4|, |w123| <= rn, |w4| = |r(c)| <= m + |d|/|n|:
+    //                                                                  6 u (rn rho + m + |d|/|n|)
+    // A hypothesis passes through a transformed point of the set, so |d|/|n| <= max_j Q_j.  The
+    // FP64 arithmetic on either side stays below 2^-45 of these magnitudes; the slack covers it.
+    // The matrix pipe may flush denormal operands and results: an absolute 1e-30 covers that.
+    constexpr double kSlack = 1.25;
+    const double u24 = 0x1p-24;
+    std::vector<double> Q((size_t)C), mj((size_t)C);
+    double Qmax = 0.0;
+    for (int j = 0; j < C; ++j) {
+        const double* M = mats.data() + 12 * (size_t)j;
+        const double* c = cs.centres.data() + 3 * (size_t)j;
+        double m2 = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
+            m2 += q * q;
+        }
+        mj[j] = std::sqrt(m2);
+        Q[j] = mj[j] + cs.rot_norm[j] * (1.0 + 1e-9) * cs.radius[j];
+        if (!(Q[j] <= Qmax)) Qmax = Q[j];      // a NaN or infinity sticks
+    }
+    std::vector<f32x2> thr_tab((size_t)C);
+    int64_t n_pad_lo = 0;
+    for (int j = 0; j < C; ++j) {
+        const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
+        double e = kSlack * u24 * (Q[j] + 6.0 * (rn * cs.radius[j] + mj[j] + Qmax)) + 1e-30;
+        if (!(e >= 0.0) || !std::isfinite(e)) e = std::numeric_limits<double>::infinity();
+        // outward rounding to float, one more step for the conversion itself
+        float lo = (float)((double)threshold - e), hi = (float)((double)threshold + e);
+        lo = std::nextafterf(lo, -std::numeric_limits<float>::infinity());
+        hi = std::nextafterf(hi, std::numeric_limits<float>::infinity());
+        if (!((double)lo <= (double)threshold - e)) lo = -std::numeric_limits<float>::infinity();
+        if (!((double)hi >= (double)threshold + e)) hi = std::numeric_limits<float>::infinity();
+        thr_tab[j] = f32x2{lo, hi};
+        const int64_t pad = (int64_t)(cs.group_off[j + 1] - cs.group_off[j]) * kGroupPoints - (int64_t)cs.n_pts[j];
+        if (lo > 0.f) n_pad_lo += pad;          // a padding point has residual exactly 0
+    }
     FastLaunch f = plan_fast(ctx, cs, n_hyp, kCandPerBlock);
+    const size_t part_words = (size_t)f.n_splits * f.n_padded;
     CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)C * f.n_ctiles * 64 * sizeof(float)));
-    CCAL_HIP(ctx, ctx->partial_buf.ensure((size_t)f.n_splits * f.n_padded * sizeof(unsigned long long)));
-    CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_hyp * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->partial_buf.ensure(2 * part_words * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->cost_buf.ensure(2 * (size_t)n_hyp * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->tbl_buf.ensure(thr_tab.size() * sizeof(f32x2)));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, thr_tab.data(), thr_tab.size() * sizeof(f32x2),
+                                 hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(wgen_planes_kernel, dim3((unsigned)((f.n_padded + 255) / 256)), dim3(256), 0,
                        ctx->stream, ctx->rec_buf.as<double>(), n_hyp, f.n_ctiles, C,
                        ctx->mats_buf.as<double>(), cs.centres_dev.as<double>(),
@@ -99,12 +149,13 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
     hipLaunchKernelGGL(inlier_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
                        dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(), cs.groups.as<f32x4>(),
                        cs.group_off_dev.as<int>(), ctx->partial_buf.as<unsigned long long>(),
-                       threshold, C, f.n_ctiles, f.n_splits);
-    hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
-                       ctx->stream, ctx->partial_buf.as<unsigned long long>(), f.n_padded,
-                       f.n_splits, (int64_t)n_hyp, ctx->cost_buf.as<unsigned long long>());
+                       ctx->tbl_buf.as<f32x2>(), C, f.n_ctiles, f.n_splits);
+    for (int k = 0; k < 2; ++k)
+        hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
+                           ctx->stream, ctx->partial_buf.as<unsigned long long>() + k * part_words, f.n_padded,
+                           f.n_splits, (int64_t)n_hyp, ctx->cost_buf.as<unsigned long long>() + (size_t)k * n_hyp);
     CCAL_HIP(ctx, hipGetLastError());
-    std::vector<unsigned long long> fast(n_hyp);
+    std::vector<unsigned long long> fast(2 * (size_t)n_hyp);
     std::vector<double> planes((size_t)n_hyp * kHypStride);
     CCAL_HIP(ctx, hipMemcpyAsync(fast.data(), ctx->cost_buf.p, fast.size() * sizeof(unsigned long long),
                                  hipMemcpyDeviceToHost, ctx->stream));
@@ -112,37 +163,60 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                                  hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-    // zero padding points have residual 0 and were counted for every hypothesis;
-    // invalid (collinear) hypotheses have w = 0 and count everything: drop them
+    // certain[h] <= (reference-arithmetic inlier count of h) <= possible[h].  Invalid (collinear)
+    // hypotheses have w = 0 and count everything: drop them.
+    unsigned long long* certain = fast.data();
+    unsigned long long* possible = fast.data() + n_hyp;
     std::vector<int> order;
-    unsigned long long best_fast = 0;
+    unsigned long long best_certain = 0;
     for (int h = 0; h < n_hyp; ++h) {
         if (planes[(size_t)h * kHypStride + 5] == 0.0) continue;
-        fast[h] -= (unsigned long long)cs.n_pad_points;
-        best_fast = std::max(best_fast, fast[h]);
+        certain[h] -= (unsigned long long)n_pad_lo;
+        possible[h] -= (unsigned long long)cs.n_pad_points;
+        best_certain = std::max(best_certain, certain[h]);
         order.push_back(h);
     }
     if (order.empty()) return fail(ctx, CCAL_ERR_ARG, "ransac_plane: every sample was collinear");
 
-    // 3. exact recount of the leaders: FP32 scoring can misplace points that sit
-    // within rounding of the threshold, so everything within a small count margin
-    // of the fast maximum is re-counted with the reference arithmetic
-    const unsigned long long margin = std::max<unsigned long long>(8, (unsigned long long)(cs.total_pts / 4096));
+    // 3. exact recount.  Only a hypothesis whose possible count reaches the best certain count can
+    // hold the most inliers; those are re-counted with the reference arithmetic, kRecount per pass
+    // over the points: first the ones with the highest certain counts, which sets a high mark, then
+    // -- in index order -- whatever that mark (most inliers so far, lowest index on ties) still
+    // cannot exclude.
     std::vector<int> leaders;
     for (int h : order)
-        if (fast[h] + margin >= best_fast) leaders.push_back(h);
+        if (possible[h] >= best_certain) leaders.push_back(h);
+    std::stable_sort(leaders.begin(), leaders.end(),
+                     [&](int a, int b) { return certain[a] > certain[b]; });
+    std::vector<int> rest;
+    if (leaders.size() > (size_t)kRecount) {
+        rest.assign(leaders.begin() + kRecount, leaders.end());
+        leaders.resize(kRecount);
+        std::sort(rest.begin(), rest.end());
+    }
     int best_h = -1;
     unsigned long long best_cnt = 0;
     std::vector<double> pl((size_t)kRecount * kPlaneStride);
     std::vector<unsigned long long> cnt(kRecount);
-    for (size_t l0 = 0; l0 < leaders.size(); l0 += kRecount) {
-        const int nb = (int)std::min<size_t>(kRecount, leaders.size() - l0);
+    CCAL_HIP(ctx, ctx->planes_buf.ensure(pl.size() * sizeof(double)));
+    CCAL_HIP(ctx, ctx->count_buf.ensure(kRecount * sizeof(unsigned long long)));
+    size_t next = 0;
+    std::vector<int> batch;
+    for (;;) {
+        batch.clear();
+        if (best_h < 0)
+            batch = leaders;
+        else
+            for (; next < rest.size() && batch.size() < (size_t)kRecount; ++next) {
+                const int h = rest[next];
+                if (possible[h] > best_cnt || (possible[h] == best_cnt && h < best_h)) batch.push_back(h);
+            }
+        if (batch.empty()) break;
+        const int nb = (int)batch.size();
         for (int k = 0; k < kRecount; ++k) {
-            const int h = leaders[l0 + (k < nb ? k : 0)];
+            const int h = batch[k < nb ? k : 0];
             for (int e = 0; e < 5; ++e) pl[(size_t)k * kPlaneStride + e] = planes[(size_t)h * kHypStride + e];
         }
-        CCAL_HIP(ctx, ctx->planes_buf.ensure(pl.size() * sizeof(double)));
-        CCAL_HIP(ctx, ctx->count_buf.ensure(kRecount * sizeof(unsigned long long)));
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl.data(), pl.size() * sizeof(double),
                                      hipMemcpyHostToDevice, ctx->stream));
         CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, kRecount * sizeof(unsigned long long), ctx->stream));
@@ -152,15 +226,12 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                                      hipMemcpyDeviceToHost, ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < nb; ++k) {
-            const int h = leaders[l0 + k];
+            const int h = batch[k];
             if (best_h < 0 || cnt[k] > best_cnt || (cnt[k] == best_cnt && h < best_h)) {
                 best_cnt = cnt[k];
                 best_h = h;
             }
         }
-        // leaders come in ascending index: once a hypothesis holds every point no later one can
-        // win (clean data makes all hypotheses tie; this stops after the first pass)
-        if (best_cnt == (unsigned long long)cs.total_pts) break;
     }
 
     // 4. refit on the winner's inliers

@@ -227,6 +227,13 @@ class OracleScene:
             n, d = e, -float(e @ (c + org))
         return np.concatenate([n, [d]]).astype(np.float32), int(inl.value), int(best.value)
 
+    def ransac_hypothesis_plane(self, pose, seed: int, h: int):
+        """(a, b, c, d, |n|) of hypothesis h, or None for a collinear sample."""
+        p = np.ascontiguousarray(pose, dtype=np.float64)
+        pl = np.empty(5)
+        ok = lib().orc_ransac_hypothesis_plane(C.byref(self.c), _d(p), int(seed), int(h), _d(pl))
+        return pl if ok else None
+
     def ransac_counts(self, pose, seed: int, threshold: float, hyps):
         """Inlier counts of the listed hypotheses over every point (host threads over points)."""
         p = np.ascontiguousarray(pose, dtype=np.float64)

@@ -623,6 +623,102 @@ def test_ransac_plane_matches_oracle(gpu_opt, oracle, outliers):
         np.testing.assert_allclose(got, s.plane, atol=2e-3)
 
 
+def _splitmix64(x):
+    m = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+def _layered_scene(rng, thr32, flat_for=None):
+    """Depth-quantised clouds: horizontal layers whose spacing is the RANSAC threshold itself, so that
+    for a hypothesis spanned by points of these layers thousands of points lie at a distance of the
+    threshold to within nanometres, or exactly.  flat_for=(n_hyp, seed): one dominant layer and a thin
+    one a threshold away on either side, arranged so that every point those hypotheses sample
+    (index = splitmix64(seed + 3h + k) mod N) belongs to the dominant layer."""
+    t = np.float32(thr32)
+    below, above = np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(1))
+    if flat_for:
+        layers = [(np.float32(0), 9000), (t, 1000), (-t, 1000)]
+        n_out, z_out = 300, (0.02, 0.08)
+    else:
+        layers = [(np.float32(0), 3000), (t, 2500), (below, 500), (above, 500), (np.float32(2) * t, 2800),
+                  (-t, 300), (np.float32(2) * t + below - t, 400), (np.float32(3) * t, 900)]
+        n_out, z_out = 1000, (-0.05, 0.08)
+    pts = []
+    for z, n in layers:
+        xy = (rng.integers(-300, 300, (n, 2)) / 1000.0).astype(np.float32)
+        pts.append(np.column_stack([xy, np.full(n, z, np.float32)]))
+    pts.append(np.column_stack([(rng.integers(-300, 300, (n_out, 2)) / 1000.0),
+                                rng.uniform(z_out[0], z_out[1], n_out)]).astype(np.float32))
+    p = np.concatenate(pts)
+    if not flat_for:
+        rng.shuffle(p)
+        return p
+    n_hyp, seed = flat_for
+    sampled = sorted({_splitmix64(seed + i) % len(p) for i in range(3 * n_hyp)} |
+                     {(_splitmix64(seed + i) + 1) % len(p) for i in range(3 * n_hyp)})
+    order = np.empty(len(p), dtype=np.int64)          # order[slot] = which point goes there
+    rest = np.setdiff1d(np.arange(len(p)), sampled)
+    perm = rng.permutation(np.arange(len(sampled), len(p)))
+    order[sampled] = np.arange(len(sampled))          # the first points are of the dominant layer
+    order[rest] = perm
+    return p[order]
+
+
+def test_ransac_points_exactly_on_the_threshold(gpu_opt, oracle):
+    """The winner is decided by the reference's strict `distance < threshold` (the sequential scan of
+    oracle/ccal_oracle.c, first found on ties) even when thousands of points sit exactly on the
+    threshold or within nanometres of it, where no FP32 score can place them: the library brackets
+    every hypothesis' count and re-counts whatever the brackets cannot exclude."""
+    thr = np.float32(0.01)
+    rng = np.random.default_rng(77)
+    B = np.stack([np.eye(4), np.eye(4)])
+    pose = np.zeros(6)
+    assert np.array_equal(oracle.pose_to_matrix(pose), np.eye(4))
+    for flat, cases in ((False, ((96, 3), (400, 2024))), (True, ((64, 5), (300, 11)))):
+        for n_hyp, seed in cases:
+            p = _layered_scene(rng, thr, flat_for=(n_hyp, seed) if flat else None)
+            cut = len(p) // 3
+            clouds = [p[:cut].copy(), p[cut:].copy()]
+            gpu_opt.upload_clouds(1, clouds, B)
+            o = oracle.OracleScene(clouds, B)
+            want, want_inl, want_h = o.ransac_plane(pose, n_hyp, float(thr), seed)
+            got, got_inl, got_h = gpu_opt.ransac_plane(pose, n_hyp, float(thr), seed, which=1)
+            assert (got_inl, got_h) == (want_inl, want_h)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+            # the scenes do what they were built for.  Thick layers: the winner is a plane through two
+            # layers a float step apart, tilted by 1e-9, which cuts the layers a threshold away in half.
+            # Flat: every hypothesis is the dominant layer's own plane, all of them tie (the first
+            # wins), and the thin layers lie at exactly the threshold, i.e. outside.
+            hyp = o.ransac_hypothesis_plane(pose, seed, want_h)
+            dist = np.abs(p.astype(np.float64) @ hyp[:3] + hyp[3]) / hyp[4]
+            assert int(np.sum(dist < np.float64(thr))) == want_inl
+            if flat:
+                assert (want_inl, want_h) == (9000, 0) and int(np.sum(dist == np.float64(thr))) == 2000
+            else:
+                assert int(np.sum(np.abs(dist - np.float64(thr)) < 1e-8)) >= 2000
+
+    # the same layers seen by tilted, displaced cameras (general matrices, nothing exact any more,
+    # but dense populations within rounding of the threshold)
+    s = make_scene(3, 10, seed=5)
+    rng = np.random.default_rng(78)
+    clouds, mats = [], []
+    for j in range(3):
+        q = _layered_scene(rng, thr).astype(np.float64)
+        M = s.base_T_flange[j] @ oracle.pose_to_matrix(s.pose_true)
+        Minv = np.linalg.inv(M)
+        clouds.append((q @ Minv[:3, :3].T + Minv[:3, 3]).astype(np.float32))
+    gpu_opt.upload_clouds(1, clouds, s.base_T_flange)
+    o = oracle.OracleScene(clouds, s.base_T_flange)
+    for n_hyp, seed in ((128, 9), (512, 10)):
+        want, want_inl, want_h = o.ransac_plane(s.pose_true, n_hyp, float(thr), seed)
+        got, got_inl, got_h = gpu_opt.ransac_plane(s.pose_true, n_hyp, float(thr), seed, which=1)
+        assert (got_inl, got_h) == (want_inl, want_h)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7)
+
+
 def test_gradient_descent_matches_oracle(gpu_opt, oracle, calib1):
     ds = [calib1["ds_%d" % i] for i in range(4)]
     gpu_opt.upload_clouds(0, ds, calib1["base_T_flange"])
