@@ -174,6 +174,7 @@ SIGNATURES = {
     "ccal_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ccal_comm_create": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_char_p, _P(C.c_void_p)]),
     "ccal_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ccal_comm_info": (C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int)]),
     "ccal_argmin_allgather": (C.c_int, [_CTX, C.c_void_p, C.c_double, C.c_int64, _D, _P(C.c_int64), _P(C.c_int)]),
     "ccal_fit_plane_lsq": (C.c_int, [_CTX, C.c_int, _D, _F]),
     "ccal_fit_plane_lsq_static": (C.c_int, [_CTX, C.c_int, _D, _F]),
@@ -463,6 +464,12 @@ class Optimizer:
         if getattr(self, "_comm", None):
             self._lib.ccal_comm_destroy(self._comm)
             self._comm = None
+
+    def comm_info(self):
+        """(world size, rank) of the communicator as RCCL itself reports them."""
+        n, k = C.c_int(0), C.c_int(-1)
+        self._check(self._lib.ccal_comm_info(self._comm, C.byref(n), C.byref(k)))
+        return int(n.value), int(k.value)
 
     def argmin_allgather(self, cost: float, index: int):
         """(best_cost, best_index, winner_rank) over all ranks' (cost, index); index < 0 = empty shard."""

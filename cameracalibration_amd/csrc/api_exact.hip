@@ -1,0 +1,393 @@
+// api_exact.hip -- the objective in the reference's own arithmetic (ccal_eval), the per-point report,
+// the FP32 screening pass with its error bound, and the profiling counters of these kernels.
+#include "ccal_internal.hpp"
+#include "kernels_exact.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <atomic>
+#include <mutex>
+#include <chrono>
+#include <limits>
+#include <new>
+#include <thread>
+
+using namespace ccal;
+
+// ---------------------------------------------------------------------------
+// exact objective
+// ---------------------------------------------------------------------------
+
+struct ExactTables {
+    const double* mats;     // [pose][cloud][12]
+    const double* planes;   // [pose][kPlaneStride]
+    double* sum;            // [pose][cloud]
+    double* max;            // [pose][cloud] or null
+};
+
+template <int W, bool kWantMax>
+static void launch_exact_chains_w(ccal_ctx* ctx, const CloudSet& cs, int n_poses, const ExactTables& t)
+{
+    hipLaunchKernelGGL((exact_chain_kernel<W, kWantMax>), dim3(n_poses * cs.n_clouds), dim3(64 * W), 0,
+                       ctx->stream, cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.cloud_pt_off_dev.as<int64_t>(), t.mats, t.planes, n_poses, cs.n_clouds,
+                       (int64_t)cs.total_pts, t.sum, kWantMax ? t.max : nullptr, cs.cloud_seg_off_dev.as<int64_t>(),
+                       cs.seg_sums.as<double>());
+}
+
+// Workgroup width by chain count (measured on 20 x 300k points: 16 waves win below ~128
+// chains, 8 up to ~512, 4 beyond).
+static void launch_exact_chains(ccal_ctx* ctx, const CloudSet& cs, int n_poses, bool want_max,
+                                const ExactTables& t)
+{
+    const int64_t chains = (int64_t)n_poses * cs.n_clouds;
+    const int64_t per_cu = chains / std::max(1, ctx->n_cu);
+    if (want_max) {
+        if (per_cu < 1) launch_exact_chains_w<16, true>(ctx, cs, n_poses, t);
+        else if (per_cu < 2) launch_exact_chains_w<8, true>(ctx, cs, n_poses, t);
+        else launch_exact_chains_w<4, true>(ctx, cs, n_poses, t);
+    } else {
+        if (per_cu < 1) launch_exact_chains_w<16, false>(ctx, cs, n_poses, t);
+        else if (per_cu < 2) launch_exact_chains_w<8, false>(ctx, cs, n_poses, t);
+        else launch_exact_chains_w<4, false>(ctx, cs, n_poses, t);
+    }
+}
+
+int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                     const double* planes4, double* cost, double* per_cloud_mean,
+                     double* per_cloud_max, bool allow_split)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost)))
+        return fail(ctx, CCAL_ERR_ARG, "eval: null argument");
+    if (!planes4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "eval: plane not set");
+    if (n_poses == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+
+    // one workgroup per (cloud, pose) chain; the batch bound only keeps the grid and the
+    // constant tables modest
+    // Pose tables and results live in pinned host memory that the kernel addresses directly: a
+    // request is one launch and one stream wait, with no copy call on either side.
+    const int max_batch = 4096;
+    for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const int nb = std::min(max_batch, n_poses - k0);
+        const size_t n_mats = (size_t)nb * C * 12, n_planes = (size_t)nb * kPlaneStride, n_out = (size_t)nb * C;
+        CCAL_HIP(ctx, ctx->exact_in.ensure((n_mats + n_planes) * sizeof(double)));
+        CCAL_HIP(ctx, ctx->exact_out.ensure(2 * n_out * sizeof(double)));
+        double* mats = ctx->exact_in.as<double>();
+        double* planes = mats + n_mats;
+        double* hsum = ctx->exact_out.as<double>();
+        double* hmax = hsum + n_out;
+        for (int k = 0; k < nb; ++k) {
+            const int src = k0 + k;
+            pose_matrices(cs, poses6 + 6 * (size_t)src, mats + (size_t)k * C * 12);
+            double* pl = planes + (size_t)k * kPlaneStride;
+            if (planes4) {
+                for (int e = 0; e < 4; ++e) pl[e] = planes4[4 * (size_t)src + e];
+            } else {
+                for (int e = 0; e < 4; ++e) pl[e] = (double)ctx->plane[e];
+            }
+            // sqrt(pow(a,2)+pow(b,2)+pow(c,2)) as at :123 / :128
+            pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+            pl[5] = 1.0 / pl[4];
+            pl[6] = (pl[4] > 0x1p-300 && pl[4] < 0x1p300) ? 1.0 : 0.0;
+            pl[7] = 0.0;
+        }
+        // Requests too small to fill the chip with whole chains cut every chain into K parts (see
+        // split_chain_kernel); hmax's slots then carry the number of segments summed twice.
+        const int64_t chains = (int64_t)nb * C;
+        // (not before some evaluation of this set has left its running sums behind: without them
+        // every segment would be summed again by one wave)
+        const bool split = ctx->chain_split && allow_split && !per_cloud_max && chains < 8 * (int64_t)ctx->n_cu &&
+                           cs.seg_sums_valid &&
+                           (int64_t)nb * cs.total_segs * (int64_t)sizeof(SegMap) <= ((int64_t)1 << 30);   // records: at most 1 GiB
+        const bool prof = ctx->profiling;
+        if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
+        if (split) {
+            // parts per chain: enough workgroups to fill the chip several times over (measured on 620
+            // chains: 4 parts 0.578 s, 8 parts 0.562 s, 12 parts 0.560 s per descent)
+            const int K = (int)std::min<int64_t>(64, std::max<int64_t>(8, (16 * (int64_t)ctx->n_cu + chains - 1) / chains));
+            CCAL_HIP(ctx, ctx->split_maps.ensure((size_t)nb * cs.total_segs * sizeof(SegMap)));
+            CCAL_HIP(ctx, ctx->split_first.ensure(n_out * sizeof(double)));
+            hipLaunchKernelGGL(split_chain_kernel, dim3((unsigned)(chains * K)), dim3(64 * kSplitWaves), 0, ctx->stream,
+                               cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
+                               cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
+                               cs.seg_sums.as<double>(), cs.total_segs, ctx->split_maps.as<SegMap>(),
+                               ctx->split_first.as<double>());
+            if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
+            hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)chains), dim3(64), 0, ctx->stream, cs.xs.as<float>(),
+                               cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
+                               cs.cloud_seg_off_dev.as<int64_t>(), mats, planes, nb, C, (int64_t)cs.total_pts, K,
+                               ctx->split_maps.as<SegMap>(), cs.total_segs, ctx->split_first.as<double>(),
+                               cs.seg_sums.as<double>(), hsum, hmax);
+        } else {
+            launch_exact_chains(ctx, cs, nb, per_cloud_max != nullptr, ExactTables{mats, planes, hsum, hmax});
+        }
+        CCAL_HIP(ctx, hipGetLastError());
+        if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (prof) {
+            float ms = 0.f, ms2 = 0.f;
+            const double pp = (double)nb * (double)cs.total_pts;
+            if (split) {
+                if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess &&
+                    hipEventElapsedTime(&ms2, ctx->prof_ev[1], ctx->prof_ev[2]) == hipSuccess) {
+                    ctx->prof.split_chain_ms += ms;
+                    ctx->prof.split_finish_ms += ms2;
+                    ctx->prof.split_pose_points += pp;
+                    ++ctx->prof.split_requests;
+                }
+            } else if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[2]) == hipSuccess) {
+                ctx->prof.whole_chain_ms += ms;
+                ctx->prof.whole_pose_points += pp;
+                ++ctx->prof.whole_requests;
+            }
+        }
+        ctx->sets[which].seg_sums_valid = true;
+        if (split) {
+            for (size_t i = 0; i < n_out; ++i) ctx->split_resummed += (int64_t)hmax[i];
+            ctx->split_segments += (int64_t)nb * (cs.total_segs - C);
+        }
+        for (int k = 0; k < nb; ++k) {
+            double error = 0.0;
+            for (int j = 0; j < C; ++j) {
+                const double mean = hsum[(size_t)k * C + j] / (double)cs.n_pts[j];  // :309
+                error += mean;
+                if (per_cloud_mean) per_cloud_mean[(size_t)(k0 + k) * C + j] = mean;
+                if (per_cloud_max) per_cloud_max[(size_t)(k0 + k) * C + j] = hmax[(size_t)k * C + j];
+            }
+            cost[k0 + k] = error / (double)C;  // :312
+        }
+    }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                         const double* planes4, double* cost, double* per_cloud_mean,
+                         double* per_cloud_max)
+{
+    // Callers that drive their own optimiser through this entry point (the reference's functor calls
+    // getError pose by pose, :419-426) send runs of nearby poses, which is what the split evaluation
+    // wants; a caller that jumps around makes it sum most segments twice.  So: split, look at how
+    // much was summed twice, and after a bad call stay with whole chains for a while (1, 2, 4, ...
+    // calls) before trying again.
+    if (!ctx) return CCAL_ERR_ARG;
+    bool allow = ctx->chain_split && !per_cloud_max;
+    if (allow && ctx->split_skip > 0) {
+        --ctx->split_skip;
+        allow = false;
+    }
+    const int64_t resummed0 = ctx->split_resummed, segments0 = ctx->split_segments;
+    const int rc = ccal::eval_exact(ctx, which, n_poses, poses6, planes4, cost, per_cloud_mean, per_cloud_max, allow);
+    const int64_t segments = ctx->split_segments - segments0;
+    if (rc == CCAL_OK && segments > 0) {
+        if ((ctx->split_resummed - resummed0) * 10 > segments) {
+            ctx->split_skip = ctx->split_penalty;
+            ctx->split_penalty = std::min(256, 2 * ctx->split_penalty);
+        } else {
+            ctx->split_penalty = 1;
+        }
+    }
+    return rc;
+}
+
+// Error budget of the screening pass against the exact objective, per cloud and pose, with
+// rho = MEAN distance of the cloud's points from its centre c (the budgets below are per point and linear
+// in |p - c|; the objective is a mean over the points), m = |M (c,1)| (the centre carried to the base
+// frame) and w4 = the folded constant (the signed distance of the centre):
+//   exact path:  rounds every transformed coordinate q_r to float (src/helpers.hpp:151), and the distance weighs
+//                coordinate r with |n_r|/|n|: the residual moves by at most
+//                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 |p - c|)
+//                                                                       (R = the 3x3 part of M)
+//   fast path:   w and p - c rounded to float (one rounding each), then three fused multiply-adds (the
+//                innermost product is by exactly 1 and does not round), each on a magnitude of at most
+//                |w123||p - c| + |w4|:  5 * 2^-24 (|w123| rho + |w4|)
+//   sums:        4 + 6 FP32 adds per partial (four points per lane, six levels of the wave reduction):
+//                10 * 2^-24 of the cloud's mean residual
+// The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
+
+int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
+                      double* cost, double* bound)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost || !bound)))
+        return fail(ctx, CCAL_ERR_ARG, "eval_screen: null argument");
+    if (!planes4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "eval_screen: plane not set");
+    if (n_poses == 0) return CCAL_OK;
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    const int C = cs.n_clouds;
+    const double u24 = 0x1p-24;
+    std::vector<double> mats((size_t)C * 12), fixed((size_t)C);
+    const int max_batch = 1024;
+    for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const int nb = std::min(max_batch, n_poses - k0);
+        CCAL_HIP(ctx, ctx->screen_in.ensure((size_t)nb * C * 4 * sizeof(float)));
+        CCAL_HIP(ctx, ctx->screen_out.ensure((size_t)nb * C * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * kScreenQuarters * nb * sizeof(double)));
+        float* w = ctx->screen_in.as<float>();
+        double* sums = ctx->screen_out.as<double>();
+        std::vector<double> budget((size_t)nb * C);
+        for (int k = 0; k < nb; ++k) {
+            const int src = k0 + k;
+            pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data());
+            double pl[4];
+            for (int e = 0; e < 4; ++e) pl[e] = planes4 ? planes4[4 * (size_t)src + e] : (double)ctx->plane[e];
+            const double inv_norm = 1.0 / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+            for (int j = 0; j < C; ++j) {
+                const double* M = mats.data() + 12 * (size_t)j;
+                const double* c = cs.centres.data() + 3 * (size_t)j;
+                double wv[4];
+                fold_plane(M, pl, pl[3], inv_norm, c, wv);
+                for (int e = 0; e < 4; ++e) w[((size_t)k * C + j) * 4 + e] = (float)wv[e];
+                // |q_i| <= |R|_2 |p_i - c| + |M (c,1)| for a transformed point and |w123 . (p_i - c)| <=
+                // |w123| |p_i - c|: both budgets are linear in |p_i - c|, and the objective is a mean over the
+                // points, so the MEAN distance from the centre enters.  R = (robot pose) * (a rotation): its
+                // 2-norm is at most that of the robot pose's 3x3 part, whatever the caller uploaded.
+                // The float rounding of the exact path acts on each coordinate of q, and the distance weighs
+                // coordinate r with |n_r| / |n|: sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 rho) -- for a plane
+                // that is roughly level this is far below |q|, which is mostly horizontal offset.
+                const double rho = cs.radius_mean[j];
+                const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
+                double ex = 0.0;
+                for (int r = 0; r < 3; ++r) {
+                    const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
+                    ex += std::fabs(pl[r]) * inv_norm * (std::fabs(q) + rn * rho);
+                }
+                const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
+                budget[(size_t)k * C + j] = u24 * ex + 5.0 * u24 * (wn * rho + std::fabs(wv[3]));
+            }
+        }
+        // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)
+        CCAL_HIP(ctx, ctx->screen_w.ensure((size_t)nb * C * 4 * sizeof(float)));
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->screen_w.p, w, (size_t)nb * C * 4 * sizeof(float), hipMemcpyHostToDevice,
+                                     ctx->stream));
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
+        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks * kScreenQuarters), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
+                           cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
+                           ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
+        hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 3) / 4), dim3(256), 0, ctx->stream,
+                           ctx->screen_partial.as<double>(), cs.cloud_block_off_dev.as<int>(), nb, C, sums);
+        CCAL_HIP(ctx, hipGetLastError());
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
+        CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->profiling) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[2]) == hipSuccess) {
+                ctx->prof.screen_ms += ms;
+                ctx->prof.screen_pose_points += (double)nb * (double)cs.total_pts;
+                ++ctx->prof.screen_requests;
+            }
+        }
+        for (int k = 0; k < nb; ++k) {
+            double f = 0.0, b = 0.0;
+            for (int j = 0; j < C; ++j) {
+                const double mean = sums[(size_t)k * C + j] / (double)cs.n_pts[j];
+                f += mean;
+                b += budget[(size_t)k * C + j] + 10.0 * u24 * mean;
+            }
+            cost[k0 + k] = f / (double)C;
+            bound[k0 + k] = std::isfinite(b) ? kScreenSlack * b / (double)C : std::numeric_limits<double>::infinity();
+        }
+    }
+    return CCAL_OK;
+}
+
+extern "C" int ccal_eval_bounded(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
+                                 const double* planes4, double* cost, double* bound)
+{
+    return ccal::eval_screen(ctx, which, n_poses, poses6, planes4, cost, bound);
+}
+
+extern "C" int ccal_set_profiling(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (on) {
+        if (int rc = bind(ctx)) return rc;
+        for (hipEvent_t& e : ctx->prof_ev)
+            if (!e) CCAL_HIP(ctx, hipEventCreate(&e));
+    }
+    ctx->profiling = on != 0;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_get_profile(ccal_ctx* ctx, ccal_profile* out, int reset)
+{
+    if (!ctx || !out) return CCAL_ERR_ARG;
+    *out = ctx->prof;
+    if (reset) ctx->prof = ccal_profile{};
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_chain_split(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    ctx->chain_split = on != 0;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_set_gd_screening(ccal_ctx* ctx, int on)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    ctx->gd_screening = on != 0;
+    return CCAL_OK;
+}
+
+extern "C" int ccal_point_errors(ccal_ctx* ctx, int which, const double pose[6], const double* plane4,
+                                 int arithmetic, double* dist_out, unsigned char* class_out)
+{
+    if (int rc = check_set(ctx, which)) return rc;
+    if (!pose || (!dist_out && !class_out)) return fail(ctx, CCAL_ERR_ARG, "point_errors: null argument");
+    if (arithmetic != CCAL_POINT_OPTIMISER && arithmetic != CCAL_POINT_VIEWER)
+        return fail(ctx, CCAL_ERR_ARG, "point_errors: unknown arithmetic selector");
+    if (!plane4 && !ctx->plane_set) return fail(ctx, CCAL_ERR_STATE, "point_errors: plane not set");
+    if (int rc = bind(ctx)) return rc;
+    const CloudSet& cs = ctx->sets[which];
+    std::vector<double> mats((size_t)cs.n_clouds * 12);
+    pose_matrices(cs, pose, mats.data());
+    double pl[kPlaneStride] = {0};
+    for (int e = 0; e < 4; ++e) pl[e] = plane4 ? plane4[e] : (double)ctx->plane[e];
+    pl[4] = std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
+    CCAL_HIP(ctx, ctx->mats_buf.ensure(mats.size() * sizeof(double)));
+    CCAL_HIP(ctx, ctx->planes_buf.ensure(sizeof pl));
+    CCAL_HIP(ctx, ctx->dist_buf.ensure(cs.total_pts * sizeof(double)));
+    CCAL_HIP(ctx, ctx->list_buf.ensure(cs.total_pts));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl, sizeof pl, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(point_error_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+                       cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
+                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), arithmetic == CCAL_POINT_VIEWER ? 1 : 0,
+                       ctx->dist_buf.as<double>(), ctx->list_buf.as<unsigned char>());
+    CCAL_HIP(ctx, hipGetLastError());
+    if (dist_out) CCAL_HIP(ctx, download_array(ctx, dist_out, ctx->dist_buf.p, cs.total_pts * sizeof(double)));
+    if (class_out) CCAL_HIP(ctx, download_array(ctx, class_out, ctx->list_buf.p, cs.total_pts));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+// The accumulation primitive of the exact path on a caller-supplied array (see ccal.h).
+extern "C" int ccal_ordered_sum(ccal_ctx* ctx, const double* values, size_t n, double* out)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (!out || (n && !values)) return fail(ctx, CCAL_ERR_ARG, "ordered_sum: null argument");
+    if (int rc = bind(ctx)) return rc;
+    CCAL_HIP(ctx, ctx->dist_buf.ensure(std::max<size_t>(n, 1) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->osum_buf.ensure(sizeof(double)));
+    CCAL_HIP(ctx, ctx->omax_buf.ensure(sizeof(double)));
+    if (n)
+        CCAL_HIP(ctx, hipMemcpyAsync(ctx->dist_buf.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(64 * kChainWaves), 0, ctx->stream, ctx->dist_buf.as<double>(),
+                       (int64_t)n, ctx->osum_buf.as<double>(), ctx->omax_buf.as<double>());
+    CCAL_HIP(ctx, hipGetLastError());
+    CCAL_HIP(ctx, hipMemcpyAsync(out, ctx->osum_buf.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+

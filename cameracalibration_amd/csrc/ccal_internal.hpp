@@ -3,8 +3,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ccal.h"
@@ -150,7 +153,88 @@ struct ccal_ctx {
 
 namespace ccal {
 
-// Host-side helpers implemented in ccal_api.hip and used by gd.cpp / ransac.
+// ---- host helpers shared by the translation units (defined in api_core.hip unless noted) ----
+
+int fail(ccal_ctx* ctx, int code, const std::string& msg);      // records msg as the context's last error
+
+#define CCAL_HIP(ctx, expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return fail((ctx), CCAL_ERR_DEVICE,                                          \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));             \
+    } while (0)
+
+// HIP events that are destroyed on every way out of a function.
+struct Events {
+    std::vector<hipEvent_t> e;
+    hipError_t create(size_t n)
+    {
+        e.assign(n, nullptr);
+        for (auto& ev : e) {
+            hipError_t rc = hipEventCreate(&ev);
+            if (rc != hipSuccess) return rc;
+        }
+        return hipSuccess;
+    }
+    hipEvent_t operator[](size_t i) const { return e[i]; }
+    ~Events() { for (auto ev : e) if (ev) (void)hipEventDestroy(ev); }
+    Events() = default;
+    Events(const Events&) = delete;
+    Events& operator=(const Events&) = delete;
+};
+
+// fn(j) for j in [0, n) on a few host threads (clouds are independent units of host work).
+template <typename Fn>
+void parallel_over(int n, Fn fn)
+{
+    const int n_threads = (int)std::min<size_t>({(size_t)n, 8, std::max(1u, std::thread::hardware_concurrency())});
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int j = next++; j < n; j = next++) fn(j); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
+
+constexpr int kPointsPerBlock = 256 * 16;  // exact path: points handled by one block
+constexpr int kNA = 8;                      // candidate tiles per wave on the fast path
+constexpr int kCandPerBlock = 4 * kNA * 16; // 512
+constexpr unsigned kBandCap = 1u << 16;     // near-minimum candidates re-scored per pass
+
+// Every rounding budget of the fast paths (screening pass, grid search) is inflated by this factor.
+constexpr double kScreenSlack = 1.25;
+
+// ccal_fit_plane_lsq_static: clouds per set it accepts, and the doubles of its static scratch array
+// (per-cloud pose rows, then the partial moments of the moment pass: kMomentGrid x kMoments).
+constexpr int kStaticMaxClouds = 1024;
+constexpr size_t kStaticScratchDoubles = (size_t)kStaticMaxClouds * 12 + (size_t)2048 * 10;
+
+struct FastLaunch {
+    int n_ctiles;
+    int64_t n_padded;
+    int64_t cand_blocks;
+    int n_splits;
+};
+
+
+int bind(ccal_ctx* ctx);                        // makes the context's GPU current
+int check_set(ccal_ctx* ctx, int which);        // the selector is valid and the set uploaded
+
+// Rows 0..2 of base_T_flange_j * F(pose) for every cloud, [n_clouds][12].
+void pose_matrices(const CloudSet& cs, const double pose[6], double* mats);
+int choose_splits(const ccal_ctx* ctx, const CloudSet& cs, int64_t cand_blocks);
+// per_block: candidates of one workgroup of the kernel the plan is for.
+FastLaunch plan_fast(const ccal_ctx* ctx, const CloudSet& cs, int64_t n, int64_t per_block);
+int64_t fast_chunk(const CloudSet& cs);
+// bf16x3 K-slot form of the point groups for the wide residual kernel (api_search.hip).
+int ensure_split_groups(ccal_ctx* ctx, CloudSet& cs);
+// This device's address of the static scratch array of ccal_fit_plane_lsq_static (api_fit.hip).
+hipError_t static_scratch_address(double** out);
+// A result array of the context's stream into the caller's (pageable) memory, through the
+// pinned staging lanes when it is large; returns with the bytes in place.
+hipError_t download_array(ccal_ctx* ctx, void* dst, const void* src, size_t bytes);
+
 // allow_split: the poses are close to those of the previous such call (a descent), so a small request
 // may cut its chains into parts whose units are guessed from that call's sums (same values either way).
 int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,

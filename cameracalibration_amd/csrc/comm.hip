@@ -28,6 +28,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -56,6 +58,8 @@ Rccl& rccl()
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
     });
     return r;
 }
@@ -137,6 +141,18 @@ extern "C" int ccal_comm_destroy(ccal_comm* c)
     return CCAL_OK;
 }
 
+// What RCCL itself says about the communicator (not what the caller passed to ccal_comm_create).
+extern "C" int ccal_comm_info(const ccal_comm* c, int* world_size, int* rank)
+{
+    if (!c || !c->comm) return CCAL_ERR_ARG;
+    Rccl& r = rccl();
+    int n = 0, k = 0;
+    if (r.CommCount(c->comm, &n) != ncclSuccess || r.CommUserRank(c->comm, &k) != ncclSuccess) return CCAL_ERR_DEVICE;
+    if (world_size) *world_size = n;
+    if (rank) *rank = k;
+    return CCAL_OK;
+}
+
 extern "C" int ccal_argmin_allgather(ccal_ctx* ctx, ccal_comm* c, double cost, int64_t index, double* best_cost,
                                      int64_t* best_index, int* winner_rank)
 {
@@ -154,6 +170,10 @@ extern "C" int ccal_argmin_allgather(ccal_ctx* ctx, ccal_comm* c, double cost, i
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return comm_fail(ctx, CCAL_ERR_DEVICE, std::string("argmin_allgather: ") + hipGetErrorString(e));
+    // a rank whose search failed still joins the exchange (nobody is left waiting) and says so
+    for (int k = 0; k < c->world; ++k)
+        if (all[k].index == CCAL_SHARD_FAILED)
+            return comm_fail(ctx, CCAL_ERR_STATE, "argmin_allgather: rank " + std::to_string(k) + " reported a failed search");
     // lexicographic (cost, index) minimum, empty shards (index < 0) skipped: the same rule as ccal_argmin_merge
     int w = -1;
     for (int k = 0; k < c->world; ++k) {

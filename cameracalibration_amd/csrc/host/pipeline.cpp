@@ -15,12 +15,15 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <fstream>
 #include <iostream>
+#include <iterator>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -174,9 +177,18 @@ struct Check {
 //   CCAL_COMM_FILE               rendezvous file: rank 0 writes the 128-byte communicator id there
 //                                (and removes it once every rank has joined), the others wait for it.
 //                                When set, the exchange runs even with one process.
+//   CCAL_COMM_NONCE              any string naming THIS job (the same on every rank).  It is stored
+//                                behind the id, and a rank accepts only a file that carries its own
+//                                nonce: a file left behind by a crashed earlier job is then never
+//                                mistaken for this job's (its id would block ncclCommInitRank for good).
+//   CCAL_COMM_TIMEOUT_S          seconds a rank waits for the file, inside ccal_comm_create and inside
+//                                the exchange before it gives up and ends the process (default 600).
+// RCCL collectives cannot be cancelled: a process whose peers never arrive can only be ended.  A
+// launcher should still end the whole job when one process dies; the deadline is the backstop.
 struct Peers {
     int world = 1, rank = 0, local_rank = 0;
-    std::string comm_file;
+    int timeout_s = 600;
+    std::string comm_file, nonce;
     bool exchange() const { return world > 1 || !comm_file.empty(); }
 };
 
@@ -190,10 +202,49 @@ Peers peers_from_env()
     p.world = geti("CCAL_WORLD_SIZE", 1);
     p.rank = geti("CCAL_RANK", 0);
     p.local_rank = geti("CCAL_LOCAL_RANK", p.rank);
+    p.timeout_s = std::max(1, geti("CCAL_COMM_TIMEOUT_S", 600));
     if (const char* f = std::getenv("CCAL_COMM_FILE")) p.comm_file = f;
+    if (const char* f = std::getenv("CCAL_COMM_NONCE")) p.nonce = f;
     if (p.world < 1 || p.rank < 0 || p.rank >= p.world) throw Failure(CCAL_ERR_ARG, "CCAL_RANK / CCAL_WORLD_SIZE out of range");
     if (p.world > 1 && p.comm_file.empty()) throw Failure(CCAL_ERR_ARG, "CCAL_WORLD_SIZE > 1 needs CCAL_COMM_FILE");
     return p;
+}
+
+// Ends the process when a collective has not returned in time (its peers died or never came).
+class Deadline {
+public:
+    Deadline(int seconds, const char* what)
+    {
+        watcher_ = std::thread([this, seconds, what]() {
+            std::unique_lock<std::mutex> lk(m_);
+            if (!cv_.wait_for(lk, std::chrono::seconds(seconds), [this]() { return done_; })) {
+                std::fprintf(stderr, "camera_calibration_optimization: %s did not complete within %d s "
+                                     "(a peer process is missing); giving up\n", what, seconds);
+                std::fflush(stderr);
+                std::_Exit(3);
+            }
+        });
+    }
+    ~Deadline()
+    {
+        { std::lock_guard<std::mutex> lk(m_); done_ = true; }
+        cv_.notify_all();
+        watcher_.join();
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool done_ = false;
+    std::thread watcher_;
+};
+
+// The rendezvous file: 128 bytes of communicator id, then the job's nonce.
+bool read_comm_file(const std::string& path, const std::string& nonce, char id[CCAL_COMM_ID_BYTES])
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f || !f.read(id, CCAL_COMM_ID_BYTES) || f.gcount() != (std::streamsize)CCAL_COMM_ID_BYTES) return false;
+    std::string tail((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return tail == nonce;
 }
 
 ccal_comm* join_peers(ccal_ctx* ctx, const Peers& p)
@@ -201,25 +252,29 @@ ccal_comm* join_peers(ccal_ctx* ctx, const Peers& p)
     char id[CCAL_COMM_ID_BYTES];
     const std::string tmp = p.comm_file + ".tmp";
     if (p.rank == 0) {
+        std::remove(p.comm_file.c_str());       // whatever an earlier job left there
         if (ccal_comm_unique_id(id) != CCAL_OK) throw Failure(CCAL_ERR_DEVICE, "ccal_comm_unique_id failed (librccl missing?)");
         {
             std::ofstream f(tmp, std::ios::binary);
             f.write(id, sizeof id);
+            f.write(p.nonce.data(), (std::streamsize)p.nonce.size());
             if (!f) throw Failure(CCAL_ERR_IO, "cannot write " + tmp);
         }
         if (std::rename(tmp.c_str(), p.comm_file.c_str()) != 0) throw Failure(CCAL_ERR_IO, "cannot create " + p.comm_file);
     } else {
         const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            std::ifstream f(p.comm_file, std::ios::binary);
-            if (f && f.read(id, sizeof id) && f.gcount() == (std::streamsize)sizeof id) break;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-                throw Failure(CCAL_ERR_IO, "no communicator id in " + p.comm_file + " after 120 s");
+        while (!read_comm_file(p.comm_file, p.nonce, id)) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(p.timeout_s))
+                throw Failure(CCAL_ERR_IO, "no communicator id of this job in " + p.comm_file + " after " +
+                                               std::to_string(p.timeout_s) + " s");
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
     ccal_comm* comm = nullptr;
-    Check{ctx}(ccal_comm_create(ctx, p.world, p.rank, id, &comm), "comm_create");
+    {
+        Deadline d(p.timeout_s, "joining the communicator");
+        Check{ctx}(ccal_comm_create(ctx, p.world, p.rank, id, &comm), "comm_create");
+    }
     if (p.rank == 0) std::remove(p.comm_file.c_str());   // every rank has read it: comm_create is collective
     return comm;
 }
@@ -255,6 +310,8 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
 {
     std::vector<ccal_ctx*> ctxs;
     ccal_comm* comm = nullptr;
+    bool exchanged = false;        // this process has taken part in the arg-min exchange
+    int comm_timeout_s = 600;
     auto cleanup = [&]() {
         if (comm) ccal_comm_destroy(comm);
         comm = nullptr;
@@ -264,6 +321,7 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
     try {
         if (!config_path) throw Failure(CCAL_ERR_ARG, "null config path");
         const Peers peers = peers_from_env();
+        comm_timeout_s = peers.timeout_s;
         const bool writer = peers.rank == 0;              // one process writes the two text files
         const bool chatty = verbose != 0 && writer;
         std::ofstream outfile, errorfile;                 // left closed on the other ranks: writes go nowhere
@@ -343,6 +401,8 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         int64_t best_index = w >= 0 ? idxs[w] : -1;
         if (comm) {
             // the one exchange between processes: (cost, index) records over RCCL, lexicographic minimum
+            Deadline d(peers.timeout_s, "the arg-min exchange");
+            exchanged = true;
             Check{ctx}(ccal_argmin_allgather(ctx, comm, best_cost, best_index, &best_cost, &best_index, nullptr),
                        "argmin_allgather");
         }
@@ -402,6 +462,14 @@ extern "C" int ccal_run_config(const char* config_path, const char* results_path
         cleanup();
         return CCAL_OK;
     } catch (const std::exception& e) {
+        if (comm && !exchanged && !ctxs.empty()) {
+            // the peers are (or will be) waiting in the exchange: join it with the failure mark, so that
+            // they return an error instead of waiting for a record that never comes
+            Deadline d(comm_timeout_s, "the arg-min exchange (reporting a failure)");
+            double c;
+            int64_t i;
+            (void)ccal_argmin_allgather(ctxs[0], comm, 1e9, CCAL_SHARD_FAILED, &c, &i, nullptr);
+        }
         cleanup();
         if (errbuf && errbuf_len) {
             std::strncpy(errbuf, e.what(), errbuf_len - 1);

@@ -1,0 +1,349 @@
+// kernels_fit.hpp -- plane fits: the moment pass of the least-squares fit and of the RANSAC refit; RANSAC hypotheses, their FP32 inlier brackets and exact recounts
+//
+// One of the kernel headers of libccal; each is included by exactly one translation unit
+// (api_fit.hip), so its __global__ functions have one definition in the library.
+#pragma once
+
+#include "kernels_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ccal {
+
+// Moments of the base-frame points q = float(M p): for the z-regression plane fit
+// (src/camera_calibration_optimization.cpp:100-119 on the cloud of :240-272) and,
+// with an inlier mask, for the RANSAC refit.  Accumulated about a fixed origin
+// `org` (an approximate centroid) so the normal equations / covariance stay well
+// conditioned in FP64.  Order of the 10 sums: 1, x, y, z, xx, xy, yy, xz, yz, zz.
+// mask: plane (a,b,c,d,|n|) and threshold; thr < 0 keeps every point.
+
+struct InlierMask {
+    double pl[5];
+    double thr;
+};
+
+// Workgroups of the moment pass: each takes a contiguous share of the 4096-point block table (a fixed
+// assignment: the partial sums, and so the result, are the same bits on every run).
+
+__host__ __device__ inline int moment_rows(int n_table) { return n_table < kMomentGrid ? n_table : kMomentGrid; }
+
+__global__ __launch_bounds__(256) void moments_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, int n_table, const double* __restrict__ mats, double ox, double oy,
+    double oz, InlierMask mask, double* __restrict__ part /* [moment_rows(n_table)][kMoments] */)
+{
+    __shared__ double sM[12];
+    __shared__ double red[4][kMoments];
+    const int rows = moment_rows(n_table);
+    const int t0 = (int)((int64_t)n_table * blockIdx.x / rows), t1 = (int)((int64_t)n_table * (blockIdx.x + 1) / rows);
+    double m[kMoments];
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) m[k] = 0.0;
+    int cloud = -1;
+    for (int t = t0; t < t1; ++t) {
+        const BlockDesc bd = blocks[t];
+        if (bd.cloud != cloud) {             // uniform over the workgroup
+            __syncthreads();
+            if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+            __syncthreads();
+            cloud = bd.cloud;
+        }
+        // four points per thread and trip: their twelve loads are in flight together (the pass is bound by
+        // HBM and FP64 issue about equally).  The transform keeps the reference's operation order (the point
+        // must be the float the optimiser sees); the moment sums are fused multiply-adds -- any order and
+        // rounding of these sums is as good as another, only the fixed order matters.
+        constexpr int kPer = 4;
+        for (int64_t i0 = bd.begin + threadIdx.x; i0 < bd.end; i0 += (int64_t)kPer * blockDim.x) {
+            float X[kPer], Y[kPer], Z[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int64_t i = i0 + (int64_t)u * blockDim.x;
+                const int64_t ic = i < bd.end ? i : bd.begin;
+                X[u] = xs[ic]; Y[u] = ys[ic]; Z[u] = zs[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                if (i0 + (int64_t)u * blockDim.x >= bd.end) continue;
+                const double xd = (double)X[u], yd = (double)Y[u], zd = (double)Z[u];
+                float q[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double p = sM[r * 4 + 3];
+                    p = xd * sM[r * 4 + 0] + p;
+                    p = yd * sM[r * 4 + 1] + p;
+                    p = zd * sM[r * 4 + 2] + p;
+                    q[r] = (float)p;
+                }
+                if (mask.thr >= 0.0) {
+                    const double num = mask.pl[0] * (double)q[0] + mask.pl[1] * (double)q[1] +
+                                       mask.pl[2] * (double)q[2] + mask.pl[3];
+                    if (!(__builtin_fabs(num) / mask.pl[4] < mask.thr)) continue;
+                }
+                const double x = (double)q[0] - ox, y = (double)q[1] - oy, z = (double)q[2] - oz;
+                m[0] += 1.0; m[1] += x; m[2] += y; m[3] += z;
+                m[4] = __builtin_fma(x, x, m[4]); m[5] = __builtin_fma(x, y, m[5]); m[6] = __builtin_fma(y, y, m[6]);
+                m[7] = __builtin_fma(x, z, m[7]); m[8] = __builtin_fma(y, z, m[8]); m[9] = __builtin_fma(z, z, m[9]);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+        double s = m[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        const int k = threadIdx.x;
+        part[(int64_t)blockIdx.x * kMoments + k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    }
+}
+
+// Sums the per-block partial moments in a fixed order (one workgroup: thread t takes rows
+// t, t + 1024, ...; then a wave tree and the 16 wave totals in wave order).
+__global__ __launch_bounds__(1024) void moments_finalize_kernel(const double* __restrict__ part,
+                                                                int n_blocks,
+                                                                double* __restrict__ out)
+{
+    __shared__ double red[16][kMoments];
+    double m[kMoments];
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) m[k] = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 1024) {
+        const double* row = part + (int64_t)b * kMoments;
+#pragma unroll
+        for (int k = 0; k < kMoments; ++k) m[k] += row[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kMoments; ++k) {
+        double s = m[k];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMoments) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+// Same contraction, counting instead of summing (RANSAC scoring).  The FP32 residual of a point
+// lies within a known distance e of the reference-arithmetic one (the caller derives e per cloud),
+// so two counts bracket the reference's inlier count of a hypothesis: points with |w.p| < thr - e
+// are inliers for certain, points with |w.p| >= thr + e are not.  thr_tab[cloud] = (thr - e, thr + e),
+// rounded outwards.  partial[0][split][candidate] = certain, partial[1][split][candidate] = possible.
+// Padding points have residual 0 and are counted wherever 0 lies below the bound; the host
+// subtracts them.  Lane counters are 32 bits wide: a lane sees 1/16 of a split's points.
+template <int NA>
+__global__ __launch_bounds__(256) void inlier_mfma_kernel(
+    const float* __restrict__ W, const f32x4* __restrict__ groups,
+    const int* __restrict__ group_off, unsigned long long* __restrict__ partial,
+    const f32x2* __restrict__ thr_tab, int n_clouds, int n_ctiles, int n_splits)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ctile0 = (blockIdx.x * 4 + wave) * NA;
+    const int split = blockIdx.y;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    unsigned int lo[NA][4], hi[NA][4];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { lo[a][r] = 0; hi[a][r] = 0; }
+
+    for (int j = 0; j < n_clouds; ++j) {
+        const int g0 = group_off[j];
+        const int G = group_off[j + 1] - g0;
+        const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
+        const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
+        if (gb >= ge) continue;
+        const f32x2 t = thr_tab[j];
+        const float tlo = t[0], thi = t[1];
+        float A[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+            A[a] = W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane];
+        const f32x4* gp = groups + (int64_t)gb * 64 + lane;
+        f32x4 b = gp[0];
+        for (int g = gb; g < ge; ++g) {
+            f32x4 bn = b;
+            if (g + 1 < ge) bn = gp[64];
+            gp += 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a], b[u], zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m = __builtin_fabsf(d[r]);
+                        lo[a][r] += (m < tlo) ? 1u : 0u;
+                        hi[a][r] += (m < thi) ? 1u : 0u;
+                    }
+                }
+            }
+            b = bn;
+        }
+    }
+    const int64_t plane = (int64_t)n_splits * n_ctiles * 16;
+    unsigned long long* out = partial + (int64_t)split * n_ctiles * 16;
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsigned long long v = lo[a][r], w = hi[a][r];
+            v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
+            v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
+            v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
+            v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
+            if ((lane & 15) == 0) {
+                const int64_t at = (int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r;
+                out[at] = v;
+                out[plane + at] = w;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void reduce_splits_u64_kernel(
+    const unsigned long long* __restrict__ partial, int64_t n_padded, int n_splits,
+    int64_t n_valid, unsigned long long* __restrict__ count)
+{
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_valid) return;
+    unsigned long long s = 0;
+    for (int k = 0; k < n_splits; ++k) s += partial[(int64_t)k * n_padded + c];
+    count[c] = s;
+}
+
+// ---------------------------------------------------------------------------
+// RANSAC plane hypotheses
+// ---------------------------------------------------------------------------
+// Counter-based generator: splitmix64 of (seed + counter).
+__host__ __device__ inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Hypothesis h samples three distinct global point indices
+//   i_k = splitmix64(seed + 3h + k) mod N   (a repeat is bumped to the next index),
+// carries them to the base frame with the reference's transform arithmetic and
+// spans the plane: n = (q1-q0) x (q2-q0) normalised with n.z >= 0, d = -n.q0.
+// planes[h] = (a,b,c,d,|n|,valid).
+constexpr int kHypStride = 8;
+
+__global__ __launch_bounds__(256) void ransac_hyp_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const int64_t* __restrict__ cloud_pt_off, int n_clouds, int64_t total_pts,
+    const double* __restrict__ mats, uint64_t seed, int n_hyp, double* __restrict__ planes)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hyp) return;
+    int64_t idx[3];
+    for (int k = 0; k < 3; ++k) {
+        int64_t v = (int64_t)(splitmix64(seed + 3ull * (uint64_t)h + (uint64_t)k) % (uint64_t)total_pts);
+        for (int t = 0; t < k; ++t)
+            if (v == idx[t]) { v = (v + 1) % total_pts; t = -1; }
+        idx[k] = v;
+    }
+    double q[3][3];
+    for (int k = 0; k < 3; ++k) {
+        int j = 0;
+        while (j + 1 < n_clouds && idx[k] >= cloud_pt_off[j + 1]) ++j;
+        const double* M = mats + 12 * j;
+        const double xd = (double)xs[idx[k]], yd = (double)ys[idx[k]], zd = (double)zs[idx[k]];
+        for (int r = 0; r < 3; ++r) {
+            double p = M[r * 4 + 3];
+            p = xd * M[r * 4 + 0] + p;
+            p = yd * M[r * 4 + 1] + p;
+            p = zd * M[r * 4 + 2] + p;
+            q[k][r] = (double)(float)p;
+        }
+    }
+    const double u[3] = {q[1][0] - q[0][0], q[1][1] - q[0][1], q[1][2] - q[0][2]};
+    const double v[3] = {q[2][0] - q[0][0], q[2][1] - q[0][1], q[2][2] - q[0][2]};
+    double n[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+    const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    double* out = planes + (int64_t)h * kHypStride;
+    if (!(len > 1e-12)) {
+        for (int e = 0; e < kHypStride; ++e) out[e] = 0.0;   // collinear sample: invalid
+        out[4] = 1.0;
+        return;
+    }
+    if (n[2] < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len;
+    out[0] = n[0]; out[1] = n[1]; out[2] = n[2];
+    out[3] = -(n[0] * q[0][0] + n[1] * q[0][1] + n[2] * q[0][2]);
+    out[4] = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    out[5] = 1.0;
+    out[6] = 0.0; out[7] = 0.0;
+}
+
+// Folded 4-vectors of every (hypothesis, cloud) for the fixed pose matrices.
+__global__ __launch_bounds__(256) void wgen_planes_kernel(const double* __restrict__ planes,
+                                                          int n_hyp, int n_ctiles, int n_clouds,
+                                                          const double* __restrict__ mats,
+                                                          const double* __restrict__ centres,
+                                                          float* __restrict__ W)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)n_ctiles * kTilePoints) return;
+    const bool valid = c < n_hyp && planes[c * kHypStride + 5] != 0.0;
+    double n[3] = {0, 0, 0}, d = 0, inv = 1;
+    if (valid) {
+        const double* pl = planes + c * kHypStride;
+        n[0] = pl[0]; n[1] = pl[1]; n[2] = pl[2]; d = pl[3];
+        inv = 1.0 / pl[4];
+    }
+    const int64_t tile = c >> 4;
+    const int col = (int)(c & 15);
+    for (int j = 0; j < n_clouds; ++j) {
+        double w[4] = {0, 0, 0, 0};
+        if (valid) fold_plane(mats + 12 * j, n, d, inv, centres + 3 * j, w);
+        float* dst = W + ((int64_t)j * n_ctiles + tile) * 64 + col;
+        dst[0] = (float)w[0];
+        dst[16] = (float)w[1];
+        dst[32] = (float)w[2];
+        dst[48] = (float)w[3];
+    }
+}
+
+// Exact inlier counts for PB hypotheses (reference-arithmetic distance < thr).
+template <int PB>
+__global__ __launch_bounds__(256) void exact_count_kernel(
+    const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
+    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
+    const double* __restrict__ planes /* PB x kPlaneStride */, double thr,
+    unsigned long long* __restrict__ counts)
+{
+    __shared__ double sM[12];
+    __shared__ double sP[PB * kPlaneStride];
+    const BlockDesc bd = blocks[blockIdx.x];
+    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+    for (int i = threadIdx.x; i < PB * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
+    __syncthreads();
+    unsigned int cnt[PB];
+#pragma unroll
+    for (int k = 0; k < PB; ++k) cnt[k] = 0;
+    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+#pragma unroll
+        for (int k = 0; k < PB; ++k)
+            cnt[k] += exact_distance(sM, sP + k * kPlaneStride, x, y, z) < thr ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+        unsigned int c = cnt[k];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+    }
+}
+
+
+} // namespace ccal

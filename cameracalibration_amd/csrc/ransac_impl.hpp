@@ -1,4 +1,4 @@
-// ransac_impl.hpp -- batched RANSAC plane fit (included at the end of ccal_api.hip).
+// ransac_impl.hpp -- batched RANSAC plane fit (included at the end of api_fit.hip).
 //
 // Parameters follow the one RANSAC call in the reference tree, getPlane at
 // src/cloud_analyzer.cpp:103-121 (SACMODEL_PLANE, SAC_RANSAC, distance threshold

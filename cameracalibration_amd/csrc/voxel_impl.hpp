@@ -1,4 +1,4 @@
-// voxel_impl.hpp -- device voxel-grid downsample (included at the end of ccal_api.hip).
+// voxel_impl.hpp -- device voxel-grid downsample (the body of api_voxel.hip).
 //
 // Stands in for pcl::VoxelGrid<PointXYZ> at src/camera_calibration_optimization.cpp:196-205
 // (leaf 0.02f) with the same definition as the host filter (csrc/host/cloud_io.cpp): PCL's

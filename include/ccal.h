@@ -224,6 +224,12 @@ int ccal_comm_create(ccal_ctx* ctx, int world_size, int rank, const char id[CCAL
 int ccal_comm_destroy(ccal_comm* comm);
 int ccal_argmin_allgather(ccal_ctx* ctx, ccal_comm* comm, double cost, int64_t index,
                           double* best_cost, int64_t* best_index, int* winner_rank);
+/* A rank whose search failed passes this index so that its peers are not left waiting in the
+ * exchange: every rank's ccal_argmin_allgather then returns CCAL_ERR_STATE. */
+#define CCAL_SHARD_FAILED (-2)
+/* Size and this process's rank of the communicator as RCCL reports them (ncclCommCount,
+ * ncclCommUserRank): evidence of how many ranks the exchange really spans. */
+int ccal_comm_info(const ccal_comm* comm, int* world_size, int* rank);
 
 /* The bound ccal_grid_search works with, for the current search mode and fast kernel: for
  * every candidate c of the grid, |ccal_grid_costs value of c - ccal_eval cost of c| <=
