@@ -79,13 +79,19 @@ class GridStats(C.Structure):
 
 
 class Profile(C.Structure):
-    """ccal_profile: device-time counters of the exact and screening passes."""
+    """ccal_profile: device-time counters of the exact and screening passes, plane fits and point report."""
 
     _fields_ = [
         ("split_chain_ms", C.c_double), ("split_finish_ms", C.c_double), ("split_pose_points", C.c_double),
         ("split_requests", C.c_int64),
         ("whole_chain_ms", C.c_double), ("whole_pose_points", C.c_double), ("whole_requests", C.c_int64),
         ("screen_ms", C.c_double), ("screen_pose_points", C.c_double), ("screen_requests", C.c_int64),
+        ("exact_host_ms", C.c_double), ("exact_wait_ms", C.c_double),
+        ("screen_host_ms", C.c_double), ("screen_wait_ms", C.c_double),
+        ("ransac_score_ms", C.c_double), ("ransac_tests", C.c_double), ("ransac_calls", C.c_int64),
+        ("ransac_recount_ms", C.c_double), ("ransac_recounted", C.c_int64),
+        ("moments_ms", C.c_double), ("moments_points", C.c_double), ("moments_calls", C.c_int64),
+        ("point_error_ms", C.c_double), ("point_error_points", C.c_double),
     ]
 
 

@@ -162,6 +162,7 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : ctx->vox) b.release();
     ctx->exact_in.release();
+    ctx->exact_mats.release();
     ctx->exact_out.release();
     ctx->screen_in.release();
     ctx->screen_out.release();
@@ -606,6 +607,15 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
             }
         cs.rot_norm[j] = off <= 1e-6 ? 1.0 + 2e-6 : std::sqrt(fro);
         if (!std::isfinite(cs.rot_norm[j])) cs.rot_norm[j] = std::numeric_limits<double>::infinity();
+    }
+    {
+        std::vector<double> cb(2 * (size_t)n_clouds);
+        for (int j = 0; j < n_clouds; ++j) {
+            cb[2 * (size_t)j] = cs.radius_mean[j];
+            cb[2 * (size_t)j + 1] = cs.rot_norm[j] * (1.0 + 1e-9);
+        }
+        CCAL_HIP(ctx, cs.bound_dev.ensure(cb.size() * sizeof(double)));
+        CCAL_HIP(ctx, hipMemcpy(cs.bound_dev.p, cb.data(), cb.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     cs.split_ready = false;
     if (ctx->fast_kernel == CCAL_FAST_BF16X3_WIDE)

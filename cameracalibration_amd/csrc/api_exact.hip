@@ -71,21 +71,30 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
 
     // one workgroup per (cloud, pose) chain; the batch bound only keeps the grid and the
     // constant tables modest
-    // Pose tables and results live in pinned host memory that the kernel addresses directly: a
-    // request is one launch and one stream wait, with no copy call on either side.
+    // Pose records, planes and results live in pinned host memory that the kernels address directly: a
+    // request is a few launches and one stream wait, with no copy call on either side.
     const int max_batch = 4096;
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const double th0 = ctx->profiling ? host_ms() : 0.0;
         const int nb = std::min(max_batch, n_poses - k0);
-        const size_t n_mats = (size_t)nb * C * 12, n_planes = (size_t)nb * kPlaneStride, n_out = (size_t)nb * C;
-        CCAL_HIP(ctx, ctx->exact_in.ensure((n_mats + n_planes) * sizeof(double)));
+        const size_t n_mats = (size_t)nb * C * 12, n_recs = (size_t)nb * kPoseRec, n_planes = (size_t)nb * kPlaneStride,
+                     n_out = (size_t)nb * C;
+        CCAL_HIP(ctx, ctx->exact_in.ensure((n_recs + n_planes) * sizeof(double)));
         CCAL_HIP(ctx, ctx->exact_out.ensure(2 * n_out * sizeof(double)));
-        double* mats = ctx->exact_in.as<double>();
-        double* planes = mats + n_mats;
+        CCAL_HIP(ctx, ctx->exact_mats.ensure(n_mats * sizeof(double)));
+        double* recs = ctx->exact_in.as<double>();
+        double* planes = recs + n_recs;
+        double* mats = ctx->exact_mats.as<double>();
         double* hsum = ctx->exact_out.as<double>();
         double* hmax = hsum + n_out;
         for (int k = 0; k < nb; ++k) {
             const int src = k0 + k;
-            pose_matrices(cs, poses6 + 6 * (size_t)src, mats + (size_t)k * C * 12);
+            // the host takes the sines and cosines (libm's sincos, as the reference's binary does); the
+            // matrices of every (pose, cloud) are composed on the device from them (pose_table_kernel)
+            const double* pose = poses6 + 6 * (size_t)src;
+            const SinCos3 sc = sincos_of_pose(pose);
+            double* r = recs + (size_t)k * kPoseRec;
+            for (int e = 0; e < 3; ++e) { r[e] = pose[e]; r[3 + e] = sc.s[e]; r[6 + e] = sc.c[e]; }
             double* pl = planes + (size_t)k * kPlaneStride;
             if (planes4) {
                 for (int e = 0; e < 4; ++e) pl[e] = planes4[4 * (size_t)src + e];
@@ -107,6 +116,8 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
                            cs.seg_sums_valid &&
                            (int64_t)nb * cs.total_segs * (int64_t)sizeof(SegMap) <= ((int64_t)1 << 30);   // records: at most 1 GiB
         const bool prof = ctx->profiling;
+        hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, ctx->stream, recs,
+                           cs.base_dev.as<double>(), nb, C, mats);
         if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
         if (split) {
             // parts per chain: enough workgroups to fill the chip several times over (measured on 620
@@ -130,7 +141,9 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
         }
         CCAL_HIP(ctx, hipGetLastError());
         if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
+        const double th1 = prof ? host_ms() : 0.0;
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double th2 = prof ? host_ms() : 0.0;
         if (prof) {
             float ms = 0.f, ms2 = 0.f;
             const double pp = (double)nb * (double)cs.total_pts;
@@ -162,6 +175,10 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
                 if (per_cloud_max) per_cloud_max[(size_t)(k0 + k) * C + j] = hmax[(size_t)k * C + j];
             }
             cost[k0 + k] = error / (double)C;  // :312
+        }
+        if (prof) {
+            ctx->prof.exact_host_ms += (th1 - th0) + (host_ms() - th2);
+            ctx->prof.exact_wait_ms += th2 - th1;
         }
     }
     return CCAL_OK;
@@ -205,10 +222,10 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 //                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 |p - c|)
 //                                                                       (R = the 3x3 part of M)
 //   fast path:   w and p - c rounded to float (one rounding each), then three fused multiply-adds (the
-//                innermost product is by exactly 1 and does not round), each on a magnitude of at most
+//                constant is the innermost addend), each on a magnitude of at most
 //                |w123||p - c| + |w4|:  5 * 2^-24 (|w123| rho + |w4|)
-//   sums:        4 + 6 FP32 adds per partial (four points per lane, six levels of the wave reduction):
-//                10 * 2^-24 of the cloud's mean residual
+//   sums:        8 + 6 FP32 adds per partial (eight points per lane, six levels of the wave reduction):
+//                kScreenLaneAdds * 2^-24 of the cloud's mean residual
 // The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.
 
 int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
@@ -223,59 +240,44 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
     const CloudSet& cs = ctx->sets[which];
     const int C = cs.n_clouds;
     const double u24 = 0x1p-24;
-    std::vector<double> mats((size_t)C * 12), fixed((size_t)C);
     const int max_batch = 1024;
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
+        const double th0 = ctx->profiling ? host_ms() : 0.0;
         const int nb = std::min(max_batch, n_poses - k0);
-        CCAL_HIP(ctx, ctx->screen_in.ensure((size_t)nb * C * 4 * sizeof(float)));
-        CCAL_HIP(ctx, ctx->screen_out.ensure((size_t)nb * C * sizeof(double)));
-        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * kScreenQuarters * nb * sizeof(double)));
-        float* w = ctx->screen_in.as<float>();
+        // pinned: one record per pose in, per-(pose, cloud) sums and budgets out; the device builds the
+        // four-vectors and the budgets from the records (screen_prep_kernel), the host only takes the
+        // sines and cosines (libm, as for every pose matrix of the library)
+        CCAL_HIP(ctx, ctx->screen_in.ensure((size_t)nb * kScreenRec * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_out.ensure(2 * (size_t)nb * C * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * kScreenParts * nb * sizeof(double)));
+        CCAL_HIP(ctx, ctx->screen_w.ensure((size_t)nb * C * 4 * sizeof(float)));
+        double* recs = ctx->screen_in.as<double>();
         double* sums = ctx->screen_out.as<double>();
-        std::vector<double> budget((size_t)nb * C);
+        double* budget = sums + (size_t)nb * C;
         for (int k = 0; k < nb; ++k) {
             const int src = k0 + k;
-            pose_matrices(cs, poses6 + 6 * (size_t)src, mats.data());
-            double pl[4];
-            for (int e = 0; e < 4; ++e) pl[e] = planes4 ? planes4[4 * (size_t)src + e] : (double)ctx->plane[e];
-            const double inv_norm = 1.0 / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
-            for (int j = 0; j < C; ++j) {
-                const double* M = mats.data() + 12 * (size_t)j;
-                const double* c = cs.centres.data() + 3 * (size_t)j;
-                double wv[4];
-                fold_plane(M, pl, pl[3], inv_norm, c, wv);
-                for (int e = 0; e < 4; ++e) w[((size_t)k * C + j) * 4 + e] = (float)wv[e];
-                // |q_i| <= |R|_2 |p_i - c| + |M (c,1)| for a transformed point and |w123 . (p_i - c)| <=
-                // |w123| |p_i - c|: both budgets are linear in |p_i - c|, and the objective is a mean over the
-                // points, so the MEAN distance from the centre enters.  R = (robot pose) * (a rotation): its
-                // 2-norm is at most that of the robot pose's 3x3 part, whatever the caller uploaded.
-                // The float rounding of the exact path acts on each coordinate of q, and the distance weighs
-                // coordinate r with |n_r| / |n|: sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 rho) -- for a plane
-                // that is roughly level this is far below |q|, which is mostly horizontal offset.
-                const double rho = cs.radius_mean[j];
-                const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
-                double ex = 0.0;
-                for (int r = 0; r < 3; ++r) {
-                    const double q = M[r * 4] * c[0] + M[r * 4 + 1] * c[1] + M[r * 4 + 2] * c[2] + M[r * 4 + 3];
-                    ex += std::fabs(pl[r]) * inv_norm * (std::fabs(q) + rn * rho);
-                }
-                const double wn = std::sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
-                budget[(size_t)k * C + j] = u24 * ex + 5.0 * u24 * (wn * rho + std::fabs(wv[3]));
-            }
+            const double* pose = poses6 + 6 * (size_t)src;
+            const SinCos3 sc = sincos_of_pose(pose);
+            double* r = recs + (size_t)k * kScreenRec;
+            for (int e = 0; e < 3; ++e) { r[e] = pose[e]; r[3 + e] = sc.s[e]; r[6 + e] = sc.c[e]; }
+            for (int e = 0; e < 4; ++e) r[9 + e] = planes4 ? planes4[4 * (size_t)src + e] : (double)ctx->plane[e];
+            r[13] = 1.0 / std::sqrt(r[9] * r[9] + r[10] * r[10] + r[11] * r[11]);
+            r[14] = r[15] = 0.0;
         }
-        // every block reads the whole table: it goes to device memory first (one small copy from pinned memory)
-        CCAL_HIP(ctx, ctx->screen_w.ensure((size_t)nb * C * 4 * sizeof(float)));
-        CCAL_HIP(ctx, hipMemcpyAsync(ctx->screen_w.p, w, (size_t)nb * C * 4 * sizeof(float), hipMemcpyHostToDevice,
-                                     ctx->stream));
+        hipLaunchKernelGGL(screen_prep_kernel, dim3((nb * C + 63) / 64), dim3(64), 0, ctx->stream, recs,
+                           cs.base_dev.as<double>(), cs.centres_dev.as<double>(), cs.bound_dev.as<double>(), nb, C,
+                           ctx->screen_w.as<f32x4>(), budget);
         if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
-        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks * kScreenQuarters), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
+        hipLaunchKernelGGL(screen_cost_kernel, dim3(cs.n_blocks * kScreenParts), dim3(256), 0, ctx->stream, cs.groups.as<f32x4>(),
                            cs.group_off_dev.as<int>(), cs.cloud_pt_off_dev.as<int64_t>(), cs.blocks.as<BlockDesc>(),
                            ctx->screen_w.as<f32x4>(), nb, C, ctx->screen_partial.as<double>());
         hipLaunchKernelGGL(screen_reduce_kernel, dim3((nb * C + 3) / 4), dim3(256), 0, ctx->stream,
                            ctx->screen_partial.as<double>(), cs.cloud_block_off_dev.as<int>(), nb, C, sums);
         CCAL_HIP(ctx, hipGetLastError());
         if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[2], ctx->stream));
+        const double th1 = ctx->profiling ? host_ms() : 0.0;
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double th2 = ctx->profiling ? host_ms() : 0.0;
         if (ctx->profiling) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[2]) == hipSuccess) {
@@ -289,10 +291,14 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
             for (int j = 0; j < C; ++j) {
                 const double mean = sums[(size_t)k * C + j] / (double)cs.n_pts[j];
                 f += mean;
-                b += budget[(size_t)k * C + j] + 10.0 * u24 * mean;
+                b += budget[(size_t)k * C + j] + (double)kScreenLaneAdds * u24 * mean;
             }
             cost[k0 + k] = f / (double)C;
             bound[k0 + k] = std::isfinite(b) ? kScreenSlack * b / (double)C : std::numeric_limits<double>::infinity();
+        }
+        if (ctx->profiling) {
+            ctx->prof.screen_host_ms += (th1 - th0) + (host_ms() - th2);
+            ctx->prof.screen_wait_ms += th2 - th1;
         }
     }
     return CCAL_OK;
@@ -360,15 +366,24 @@ extern "C" int ccal_point_errors(ccal_ctx* ctx, int which, const double pose[6],
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
                                  hipMemcpyHostToDevice, ctx->stream));
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl, sizeof pl, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
     hipLaunchKernelGGL(point_error_kernel, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
                        cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
                        ctx->planes_buf.as<double>(), arithmetic == CCAL_POINT_VIEWER ? 1 : 0,
                        ctx->dist_buf.as<double>(), ctx->list_buf.as<unsigned char>());
     CCAL_HIP(ctx, hipGetLastError());
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
     if (dist_out) CCAL_HIP(ctx, download_array(ctx, dist_out, ctx->dist_buf.p, cs.total_pts * sizeof(double)));
     if (class_out) CCAL_HIP(ctx, download_array(ctx, class_out, ctx->list_buf.p, cs.total_pts));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess) {
+            ctx->prof.point_error_ms += ms;
+            ctx->prof.point_error_points += (double)cs.total_pts;
+        }
+    }
     return CCAL_OK;
 }
 

@@ -101,16 +101,26 @@ extern "C" int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6]
     CCAL_HIP(ctx, ctx->osum_buf.ensure(kMoments * sizeof(double)));
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->mats_buf.p, mats.data(), mats.size() * sizeof(double),
                                  hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
     hipLaunchKernelGGL(moments_kernel, dim3(moment_rows(cs.n_blocks)), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
                        cs.blocks.as<BlockDesc>(), cs.n_blocks, ctx->mats_buf.as<double>(), org[0], org[1],
                        org[2], InlierMask{{0, 0, 0, 0, 1}, -1.0}, ctx->psum_buf.as<double>());
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
     hipLaunchKernelGGL(moments_finalize_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->psum_buf.as<double>(), moment_rows(cs.n_blocks), ctx->osum_buf.as<double>());
     CCAL_HIP(ctx, hipGetLastError());
     double m[kMoments];
     CCAL_HIP(ctx, hipMemcpyAsync(m, ctx->osum_buf.p, sizeof m, hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess) {
+            ctx->prof.moments_ms += ms;
+            ctx->prof.moments_points += (double)cs.total_pts;
+            ++ctx->prof.moments_calls;
+        }
+    }
     return plane_from_moments(ctx, m, org, plane_out, "fit_plane_lsq");
 }
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <thread>
@@ -100,6 +101,7 @@ struct CloudSet {
     bool split_ready = false;          // built on first selection of that kernel
     std::vector<int> group_off;        // n_clouds + 1
     std::vector<double> centres;       // n_clouds * 3
+    DevBuf bound_dev;                  // per cloud: radius_mean and rot_norm (1 + 1e-9), for the screening budget
     DevBuf radius_dev;                 // per cloud: bits of the largest squared distance from the centre
     std::vector<double> radius;        // per cloud: that distance (infinity if a point is not finite)
     std::vector<double> radius_mean;   // per cloud: mean distance from the centre (same convention)
@@ -112,7 +114,7 @@ struct CloudSet {
     {
         xs.release(); ys.release(); zs.release(); blocks.release();
         cloud_block_off_dev.release(); cloud_pt_off_dev.release(); cloud_seg_off_dev.release(); seg_sums.release(); groups.release(); group_off_dev.release();
-        scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release(); radius_dev.release();
+        scale_dev.release(); centres_dev.release(); base_dev.release(); split_groups.release(); radius_dev.release(); bound_dev.release();
         ready = false;
     }
 };
@@ -134,7 +136,8 @@ struct ccal_ctx {
     ccal::DevBuf w_buf, partial_buf, cost_buf, rec_buf, minrec_buf, list_buf, count_buf;
     ccal::DevBuf sep_wr, sep_sb, sep_perm, sep_tab, sep_meta, sep_wcnt, sep_wsum;
     ccal::DevBuf vox[13];                // scratch of the device voxel grid
-    ccal::HostBuf exact_in, exact_out;   // pose tables and per-chain results of the exact objective
+    ccal::HostBuf exact_in, exact_out;   // pose records + planes, and per-chain results of the exact objective
+    ccal::DevBuf exact_mats;             // [pose][cloud][12]: the rows of base_T_flange_j * F(pose), built on the device
     ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation
     bool chain_split = true;             // small exact requests cut every chain into parts
     int64_t split_resummed = 0, split_segments = 0;   // statistics of the split evaluations
@@ -183,6 +186,12 @@ struct Events {
     Events(const Events&) = delete;
     Events& operator=(const Events&) = delete;
 };
+
+// Host wall clock in milliseconds (the host-side counters of ccal_profile).
+inline double host_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // fn(j) for j in [0, n) on a few host threads (clouds are independent units of host work).
 template <typename Fn>

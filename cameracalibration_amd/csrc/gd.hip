@@ -112,8 +112,9 @@ struct Machine {
     // few dozen poses than for one
     int planned_screen() const
     {
-        // the pass works through the poses in tiles of 16: a started tile costs the same full or not
-        int want = (last_trials + 3 + 15) / 16 * 16;
+        // the pass works through the poses in tiles of 16, with one of 8 at the end when that is all
+        // that is left: a started tile costs the same full or not
+        int want = (last_trials + 3 + 7) / 8 * 8;
         if (!first_request) want = 16;
         if (want > kMaxSpeculated) want = kMaxSpeculated;
         int n = 1;

@@ -14,18 +14,52 @@ namespace ccal {
 // Screening pass: the folded FP32 objective of a few poses, one pass over the points
 // ---------------------------------------------------------------------------
 // sum_i |w.(p_i - c, 1)| per (pose, cloud) for up to a few dozen poses at once: every lane keeps
-// 4 points in registers and walks the poses in tiles of kScreenTile (the four-vectors are uniform:
-// scalar loads).  Roundings per residual: four (three fused multiply-adds and a product); per
-// partial sum: 4 FP32 adds in the lane and 6 in the wave reduction; everything after that is
-// FP64 in a fixed order.  The caller turns these counts into an error bound.
-struct BlockDesc;
+// 8 points in registers and walks the poses in tiles of kScreenTile (the four-vectors are uniform:
+// scalar loads).  Roundings per residual: three fused multiply-adds (the constant enters as the
+// innermost addend); per partial sum: 8 FP32 adds in the lane and 6 in the wave reduction;
+// everything after that is FP64 in a fixed order.  The caller turns these counts into an error bound.
 constexpr int kScreenTile = 16;
-constexpr int kScreenQuarters = 4;      // workgroups per block of the table, see screen_cost_kernel
+constexpr int kScreenParts = 2;         // workgroups per block of the table, see screen_cost_kernel
+constexpr int kScreenLaneAdds = 8 + 6;  // FP32 adds behind a value that leaves a wave
 
-__global__ __launch_bounds__(256) void screen_cost_kernel(
-    const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
-    const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w /* [pose][cloud] */, int n_poses,
-    int n_clouds, double* __restrict__ partial /* [block * kScreenQuarters + quarter][pose] */);
+// The four-vectors of a screening request and their share of the error budget, one thread per
+// (pose, cloud), from one record per pose: t[3], sin[3], cos[3] of the pose (the host takes the sines
+// and cosines), plane a, b, c, d and 1 / |n|.  Same expressions as the host's pose algebra.
+//   budget = 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + rn rho)  +  5 * 2^-24 (|w123| rho + |w4|)
+// (reference side: every transformed coordinate rounded to float; fast side: w and p - c rounded to
+// float and three fused multiply-adds; rho = mean distance of the cloud's points from its centre c,
+// rn >= the 2-norm of the 3x3 part of M).
+constexpr int kScreenRec = 16;          // doubles per pose record (14 used)
+
+__global__ __launch_bounds__(64) void screen_prep_kernel(
+    const double* __restrict__ recs, const double* __restrict__ base_T_flange, const double* __restrict__ centres,
+    const double* __restrict__ cloud_bound /* [cloud]: rho, rn */, int n_poses, int n_clouds,
+    f32x4* __restrict__ W /* [pose][cloud] */, double* __restrict__ budget /* [pose][cloud] */)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_poses * n_clouds) return;
+    const int k = i / n_clouds, j = i % n_clouds;
+    const double* r = recs + (int64_t)k * kScreenRec;
+    const double t[3] = {r[0], r[1], r[2]}, sn[3] = {r[3], r[4], r[5]}, cs[3] = {r[6], r[7], r[8]};
+    const double pl[4] = {r[9], r[10], r[11], r[12]};
+    const double inv_norm = r[13];
+    double R[9], M[12], wv[4];
+    rotation_zyx(sn, cs, R);
+    compose_rows(base_T_flange + 16 * (int64_t)j, R, t, M);
+    const double* c = centres + 3 * (int64_t)j;
+    fold_plane(M, pl, pl[3], inv_norm, c, wv);
+    const f32x4 w4 = {(float)wv[0], (float)wv[1], (float)wv[2], (float)wv[3]};
+    W[i] = w4;
+    const double rho = cloud_bound[2 * j], rn = cloud_bound[2 * j + 1];
+    double ex = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double q = M[a * 4] * c[0] + M[a * 4 + 1] * c[1] + M[a * 4 + 2] * c[2] + M[a * 4 + 3];
+        ex += __builtin_fabs(pl[a]) * inv_norm * (__builtin_fabs(q) + rn * rho);
+    }
+    const double wn = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
+    budget[i] = 0x1p-24 * ex + 5.0 * 0x1p-24 * (wn * rho + __builtin_fabs(wv[3]));
+}
 
 // out[pose * n_clouds + cloud] = sum of the cloud's block partials; one wave per (pose, cloud): lane l adds
 // the partials l, l + 64, ... in order, then the lanes combine in a fixed tree (the same bits on every run).
@@ -38,31 +72,32 @@ __global__ __launch_bounds__(256) void screen_reduce_kernel(const double* __rest
     if (i >= n_poses * n_clouds) return;
     const int p = i / n_clouds, j = i % n_clouds;
     double s = 0.0;
-    for (int b = kScreenQuarters * cloud_block_off[j] + lane; b < kScreenQuarters * cloud_block_off[j + 1]; b += 64)
+    for (int b = kScreenParts * cloud_block_off[j] + lane; b < kScreenParts * cloud_block_off[j + 1]; b += 64)
         s += partial[(int64_t)b * n_poses + p];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) out[i] = s;
 }
 
-// ---------------------------------------------------------------------------
-// Exact path
-// ---------------------------------------------------------------------------
-
-// Totals over the 64 lanes of a wave of 16 values per lane at once: the 16 lanes of a row reduce-scatter
-// (four exchange steps: a lane keeps one half of its values and adds the partner's copy of that half), then
-// the four rows are added; lane l returns the total of value l & 15.  Six FP32 adds per total, as a
-// butterfly per value would take, for a third of the instructions.
-__device__ inline float wave_sum16(const float (&v)[16], int lane)
+// Totals over the 64 lanes of a wave of T (16 or 8) values per lane at once: the T lanes of a group
+// reduce-scatter (a lane keeps one half of its values and adds the partner's copy of that half, log2 T
+// exchange steps), then the 64 / T groups are added; lane l returns the total of value l & (T - 1).
+// Six FP32 adds per total either way, as a butterfly per value would take, for a third of the instructions.
+template <int T>
+__device__ inline float wave_sum_tile(const float (&v)[T], int lane)
 {
-    const int col = lane & 15;
+    static_assert(T == 16 || T == 8, "tiles of 16 or 8 values");
+    const int col = lane & (T - 1);
     float w8[8], w4[4], w2[2];
-    {
+    if constexpr (T == 16) {
         const bool hi = (col & 8) != 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float keep = hi ? v[8 + i] : v[i], give = hi ? v[i] : v[8 + i];
             w8[i] = keep + __shfl_xor(give, 8, 64);
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w8[i] = v[i];
     }
     {
         const bool hi = (col & 4) != 0;
@@ -82,30 +117,76 @@ __device__ inline float wave_sum16(const float (&v)[16], int lane)
     }
     const bool hi = (col & 1) != 0;
     float r = (hi ? w2[1] : w2[0]) + __shfl_xor(hi ? w2[0] : w2[1], 1, 64);
+    if constexpr (T == 8) r += __shfl_xor(r, 8, 64);
     r += __shfl_xor(r, 16, 64);
     r += __shfl_xor(r, 32, 64);
     return r;
 }
 
-// A workgroup takes a quarter of a block of the table (kScreenQuarters per block: 1024 points, four per
-// lane): with whole blocks the benchmark's 1465 workgroups were one and a half rounds of what the chip holds
-// at once, and every round began with all of them waiting for their loads.
+// One tile of T poses p0 .. p0 + T - 1 over the eight points of every lane; a short last tile repeats
+// its last pose.  kRagged: some of the workgroup's point slots are padding or lie beyond the cloud (their
+// coordinates are zero and their row of ones, O, is zero too); otherwise every slot is a point and the
+// constant enters the chain as it is.  Either way a residual is fma(w0, x, fma(w1, y, fma(w2, z, w3))).
+template <int T, bool kRagged>
+__device__ inline void screen_tile(const f32x4 (&X)[2], const f32x4 (&Y)[2], const f32x4 (&Z)[2], const f32x4 (&O)[2],
+                                   const f32x4* __restrict__ w, int n_clouds, int j, int p0, int n_poses,
+                                   float (*red)[kScreenTile], double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int p = p0 + t < n_poses ? p0 + t : n_poses - 1;
+        const f32x4 wv = w[(int64_t)p * n_clouds + j];
+        // two residuals per instruction (packed FP32); the lane adds them in point order
+        const f32x2 w0 = {wv[0], wv[0]}, w1 = {wv[1], wv[1]}, w2 = {wv[2], wv[2]}, w3 = {wv[3], wv[3]};
+        float a = 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 4; h += 2) {
+                const f32x2 x = {X[g][h], X[g][h + 1]}, y = {Y[g][h], Y[g][h + 1]}, z = {Z[g][h], Z[g][h + 1]};
+                f32x2 c = w3;
+                if constexpr (kRagged) {
+                    const f32x2 o = {O[g][h], O[g][h + 1]};
+                    c = w3 * o;            // exact: o is 0 or 1
+                }
+                const f32x2 r = __builtin_elementwise_fma(w0, x, __builtin_elementwise_fma(w1, y,
+                                __builtin_elementwise_fma(w2, z, c)));
+                a += __builtin_fabsf(r[0]);
+                a += __builtin_fabsf(r[1]);
+            }
+        acc[t] = a;
+    }
+    const float tot = wave_sum_tile<T>(acc, lane);
+    if (lane < T) red[wave][lane] = tot;
+    __syncthreads();
+    if (threadIdx.x < T && p0 + (int)threadIdx.x < n_poses) {
+        const int t = threadIdx.x;
+        out[p0 + t] = (((double)red[0][t] + (double)red[1][t]) + (double)red[2][t]) + (double)red[3][t];
+    }
+    __syncthreads();
+}
 
+// A workgroup takes half a block of the table (kScreenParts per block: 2048 points, eight per lane --
+// two groups, so that the wave reduction of a tile is shared by twice the points; with whole blocks the
+// benchmark's 1465 workgroups were one and a half rounds of what the chip holds at once, and every round
+// began with all of them waiting for their loads).  Tiles of 16 poses, and one of 8 when no more are left.
 __global__ __launch_bounds__(256) void screen_cost_kernel(
     const f32x4* __restrict__ groups, const int* __restrict__ group_off, const int64_t* __restrict__ cloud_pt_off,
-    const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w, int n_poses, int n_clouds,
-    double* __restrict__ partial /* [block * kScreenQuarters + quarter][pose] */)
+    const BlockDesc* __restrict__ blocks, const f32x4* __restrict__ w /* [pose][cloud] */, int n_poses, int n_clouds,
+    double* __restrict__ partial /* [block * kScreenParts + part][pose] */)
 {
     __shared__ float red[4][kScreenTile];
-    const BlockDesc bd = blocks[blockIdx.x / kScreenQuarters];
-    const int quarter = blockIdx.x % kScreenQuarters;
+    constexpr int kPartGroups = 64 / kScreenParts;      // a block of the table is 4096 consecutive points = 64 groups
+    const BlockDesc bd = blocks[blockIdx.x / kScreenParts];
+    const int part = blockIdx.x % kScreenParts;
     const int j = bd.cloud;
-    // a block of the table is 4096 consecutive points of one cloud = 64 groups
     const int64_t lb = bd.begin - cloud_pt_off[j], le = bd.end - cloud_pt_off[j];
-    const int g0 = group_off[j] + (int)(lb / kGroupPoints) + quarter * 16;
+    const int g0 = group_off[j] + (int)(lb / kGroupPoints) + part * kPartGroups;
     const int g1 = group_off[j] + (int)((le + kGroupPoints - 1) / kGroupPoints);
     double* out = partial + (int64_t)blockIdx.x * n_poses;
-    if (g0 >= g1) {                                   // a short last block: nothing in this quarter
+    if (g0 >= g1) {                                   // a short last block: nothing in this part
         for (int p = threadIdx.x; p < n_poses; p += 256) out[p] = 0.0;
         return;
     }
@@ -114,45 +195,52 @@ __global__ __launch_bounds__(256) void screen_cost_kernel(
     // The fourth row of a group (1 for a point, 0 for padding) is not loaded: it follows from the point's index.
     const int64_t n_j = cloud_pt_off[j + 1] - cloud_pt_off[j];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 X = zero, Y = zero, Z = zero, O = zero;      // absent groups add |0|
-    const int g = g0 + wave * 4 + gsel;
-    if (g < g1) {
-        const f32x4* gp = groups + (int64_t)g * 64 + col;
-        X = gp[0]; Y = gp[16]; Z = gp[32];
-        const int64_t first = (int64_t)(g - group_off[j]) * kGroupPoints + col;
+    f32x4 X[2] = {zero, zero}, Y[2] = {zero, zero}, Z[2] = {zero, zero}, O[2] = {zero, zero};   // absent groups add |0|
 #pragma unroll
-        for (int u = 0; u < 4; ++u) O[u] = first + u * kTilePoints < n_j ? 1.f : 0.f;
-    }
-    for (int p0 = 0; p0 < n_poses; p0 += kScreenTile) {
-        float acc[kScreenTile];
+    for (int h = 0; h < 2; ++h) {
+        const int g = g0 + wave * (kPartGroups / 4) + h * 4 + gsel;
+        if (g < g1) {
+            const f32x4* gp = groups + (int64_t)g * 64 + col;
+            X[h] = gp[0]; Y[h] = gp[16]; Z[h] = gp[32];
+            const int64_t first = (int64_t)(g - group_off[j]) * kGroupPoints + col;
 #pragma unroll
-        for (int t = 0; t < kScreenTile; ++t) {
-            const int p = p0 + t < n_poses ? p0 + t : n_poses - 1;   // a short last tile repeats its last pose
-            const f32x4 wv = w[(int64_t)p * n_clouds + j];
-            // two residuals per instruction (packed FP32); each still is the chain product, fma, fma, fma,
-            // and the lane adds them in point order
-            const f32x2 w0 = {wv[0], wv[0]}, w1 = {wv[1], wv[1]}, w2 = {wv[2], wv[2]}, w3 = {wv[3], wv[3]};
-            float a = 0.f;
-#pragma unroll
-            for (int h = 0; h < 4; h += 2) {
-                const f32x2 x = {X[h], X[h + 1]}, y = {Y[h], Y[h + 1]};
-                const f32x2 z = {Z[h], Z[h + 1]}, o = {O[h], O[h + 1]};
-                const f32x2 r = __builtin_elementwise_fma(w0, x, __builtin_elementwise_fma(w1, y,
-                                __builtin_elementwise_fma(w2, z, w3 * o)));
-                a += __builtin_fabsf(r[0]);
-                a += __builtin_fabsf(r[1]);
-            }
-            acc[t] = a;
+            for (int u = 0; u < 4; ++u) O[h][u] = first + u * kTilePoints < n_j ? 1.f : 0.f;
         }
-        const float tot = wave_sum16(acc, lane);
-        if (lane < kScreenTile) red[wave][lane] = tot;
-        __syncthreads();
-        if (threadIdx.x < kScreenTile && p0 + (int)threadIdx.x < n_poses) {
-            const int t = threadIdx.x;
-            out[p0 + t] = (((double)red[0][t] + (double)red[1][t]) + (double)red[2][t]) + (double)red[3][t];
-        }
-        __syncthreads();
     }
+    // every slot of this workgroup is a point of the cloud (true for all but a cloud's last workgroup)
+    const bool full = (int64_t)(g0 - group_off[j] + kPartGroups) * kGroupPoints <= n_j;
+    int p0 = 0;
+    if (full) {
+        for (; n_poses - p0 > 8; p0 += 16) screen_tile<16, false>(X, Y, Z, O, w, n_clouds, j, p0, n_poses, red, out);
+        if (p0 < n_poses) screen_tile<8, false>(X, Y, Z, O, w, n_clouds, j, p0, n_poses, red, out);
+    } else {
+        for (; n_poses - p0 > 8; p0 += 16) screen_tile<16, true>(X, Y, Z, O, w, n_clouds, j, p0, n_poses, red, out);
+        if (p0 < n_poses) screen_tile<8, true>(X, Y, Z, O, w, n_clouds, j, p0, n_poses, red, out);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact path
+// ---------------------------------------------------------------------------
+// Rows 0..2 of M = base_T_flange_j * F(pose) for every (pose, cloud) of a request, one thread each, from
+// one record per pose: t[3], sin[3], cos[3] (sines and cosines taken by the host's libm).  The same
+// contraction-free expressions as the host's pose_matrices, so the same bits.
+constexpr int kPoseRec = 9;
+
+__global__ __launch_bounds__(64) void pose_table_kernel(const double* __restrict__ recs,
+                                                        const double* __restrict__ base_T_flange, int n_poses,
+                                                        int n_clouds, double* __restrict__ mats /* [pose][cloud][12] */)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_poses * n_clouds) return;
+    const int k = i / n_clouds, j = i % n_clouds;
+    const double* r = recs + (int64_t)k * kPoseRec;
+    const double t[3] = {r[0], r[1], r[2]}, sn[3] = {r[3], r[4], r[5]}, cs[3] = {r[6], r[7], r[8]};
+    double R[9], M[12];
+    rotation_zyx(sn, cs, R);
+    compose_rows(base_T_flange + 16 * (int64_t)j, R, t, M);
+#pragma unroll
+    for (int e = 0; e < 12; ++e) mats[(int64_t)i * 12 + e] = M[e];
 }
 
 // a / b, correctly rounded, for b with a precomputed y = RN(1/b): two
@@ -729,9 +817,9 @@ __global__ __launch_bounds__(64 * W, 5) void exact_chain_kernel(
 #pragma unroll
     for (int i = 0; i < 7; ++i) src.pl[i] = pl[i];
     double sum, mx;
-    // the first pose's chains leave their running sums behind for a later split evaluation
+    // the last pose's chains leave their running sums behind for a later split evaluation
     chain_reduce<W, kWantMax>(src, cloud_pt_off[j], cloud_pt_off[j + 1], 0.0, sum, mx,
-                              seg_sums && k == 0 ? seg_sums + cloud_seg_off[j] : nullptr);
+                              seg_sums && k == n_poses - 1 ? seg_sums + cloud_seg_off[j] : nullptr);
     if (threadIdx.x == 0) {
         out_sum[(int64_t)k * n_clouds + j] = sum;
         if (kWantMax) out_max[(int64_t)k * n_clouds + j] = mx;
@@ -936,7 +1024,7 @@ __global__ __launch_bounds__(64) void split_finish_kernel(
     const int64_t* __restrict__ cloud_pt_off, const int64_t* __restrict__ cloud_seg_off,
     const double* __restrict__ mats, const double* __restrict__ planes, int n_poses, int n_clouds,
     int64_t total_pts, int K, const SegMap* __restrict__ maps, int64_t total_segs,
-    const double* __restrict__ first_sum, double* __restrict__ sref /* rewritten from pose 0 */,
+    const double* __restrict__ first_sum, double* __restrict__ sref /* rewritten from the last pose */,
     double* __restrict__ out_sum, double* __restrict__ out_resummed)
 {
     constexpr unsigned long long kTwo53 = 1ull << 53;
@@ -962,7 +1050,9 @@ __global__ __launch_bounds__(64) void split_finish_kernel(
 
     double s = first_sum[(int64_t)k * n_clouds + j];
     const SegMap* mp = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
-    double* ref = k == 0 ? sref + cloud_seg_off[j] : nullptr;
+    // The request's LAST pose leaves its sums behind: a descent's request ends with the stencil of the
+    // next iterate, which is where the next request's poses will lie.
+    double* ref = k == n_poses - 1 ? sref + cloud_seg_off[j] : nullptr;
     int resummed = 0;
     // 64 records per trip, one per lane; the next trip's records are in flight while this one is applied
     // (a single wave has nothing else to hide the latency behind)

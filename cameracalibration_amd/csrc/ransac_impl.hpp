@@ -146,10 +146,12 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                        ctx->stream, ctx->rec_buf.as<double>(), n_hyp, f.n_ctiles, C,
                        ctx->mats_buf.as<double>(), cs.centres_dev.as<double>(),
                        ctx->w_buf.as<float>());
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
     hipLaunchKernelGGL(inlier_mfma_kernel<kNA>, dim3((unsigned)f.cand_blocks, f.n_splits),
                        dim3(256), 0, ctx->stream, ctx->w_buf.as<float>(), cs.groups.as<f32x4>(),
                        cs.group_off_dev.as<int>(), ctx->partial_buf.as<unsigned long long>(),
                        ctx->tbl_buf.as<f32x2>(), C, f.n_ctiles, f.n_splits);
+    if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
     for (int k = 0; k < 2; ++k)
         hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
                            ctx->stream, ctx->partial_buf.as<unsigned long long>() + k * part_words, f.n_padded,
@@ -162,6 +164,14 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
     CCAL_HIP(ctx, hipMemcpyAsync(planes.data(), ctx->rec_buf.p, planes.size() * sizeof(double),
                                  hipMemcpyDeviceToHost, ctx->stream));
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess) {
+            ctx->prof.ransac_score_ms += ms;
+            ctx->prof.ransac_tests += (double)f.n_padded * (double)cs.n_groups * kGroupPoints;
+            ++ctx->prof.ransac_calls;
+        }
+    }
 
     // certain[h] <= (reference-arithmetic inlier count of h) <= possible[h].  Invalid (collinear)
     // hypotheses have w = 0 and count everything: drop them.
@@ -220,11 +230,20 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl.data(), pl.size() * sizeof(double),
                                      hipMemcpyHostToDevice, ctx->stream));
         CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, kRecount * sizeof(unsigned long long), ctx->stream));
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
         launch_exact_count<kRecount>(ctx, cs, (double)threshold);
+        if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
         CCAL_HIP(ctx, hipGetLastError());
         CCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->count_buf.p, kRecount * sizeof(unsigned long long),
                                      hipMemcpyDeviceToHost, ctx->stream));
         CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->profiling) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->prof_ev[0], ctx->prof_ev[1]) == hipSuccess) {
+                ctx->prof.ransac_recount_ms += ms;
+                ctx->prof.ransac_recounted += nb;
+            }
+        }
         for (int k = 0; k < nb; ++k) {
             const int h = batch[k];
             if (best_h < 0 || cnt[k] > best_cnt || (cnt[k] == best_cnt && h < best_h)) {

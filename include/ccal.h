@@ -322,8 +322,8 @@ int  ccal_set_gd_screening(ccal_ctx* ctx, int on);
  * guess did not fit.  Same values on or off (the ordered sum of :305 either way). */
 int  ccal_set_chain_split(ccal_ctx* ctx, int on);
 
-/* Device-time counters of the exact and screening passes (off by default; HIP events on the
- * context's stream around the kernels).  The reference times host code with its TIC/TOC macros
+/* Device-time counters of the exact and screening passes, the plane fits and the point report (off
+ * by default; HIP events on the context's stream around the kernels).  The reference times host code with its TIC/TOC macros
  * (src/helpers.hpp:222-234); this is their device-side counterpart and feeds the roofline
  * figures of the benchmark.  pose_points = sum over requests of poses x points of the set. */
 typedef struct {
@@ -337,6 +337,24 @@ typedef struct {
     double  screen_ms;           /* screen_cost_kernel + its reduction (FP32 line-search scores)  */
     double  screen_pose_points;
     int64_t screen_requests;
+    /* host side of the same requests (wall clock): before the stream wait (tables, launches), inside
+     * it, and after it (results) */
+    double  exact_host_ms, exact_wait_ms;
+    double  screen_host_ms, screen_wait_ms;
+    /* ccal_ransac_plane: the FP32 bracket pass over every (hypothesis, point) pair, and the exact
+     * recounts (hypotheses re-counted, device time of those passes) */
+    double  ransac_score_ms;
+    double  ransac_tests;        /* hypotheses x points (padding included) of the bracket passes   */
+    int64_t ransac_calls;
+    double  ransac_recount_ms;
+    int64_t ransac_recounted;
+    /* moments_kernel of ccal_fit_plane_lsq (+ its finalisation): points x 12 bytes is its traffic  */
+    double  moments_ms;
+    double  moments_points;
+    int64_t moments_calls;
+    /* point_error_kernel of ccal_point_errors (kernel only, without the copy to the host)         */
+    double  point_error_ms;
+    double  point_error_points;
 } ccal_profile;
 int ccal_set_profiling(ccal_ctx* ctx, int on);
 /* Copies the counters; reset != 0 zeroes them afterwards. */
