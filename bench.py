@@ -25,6 +25,15 @@ Printed on rank 0 as ONE JSON line; extra objects:
   roofline_gd   the exact path's part kernel during the descent (FP64 VALU issue).
   cpu_baseline  the CPU oracle (a port of the reference's serial loop) timed on
                 a bounded candidate sample of the same workload, rank 0, N = 1.
+  north_star_1gpu (N = 1)  the 100 x 10^6-point configurations on this one GPU: upload, separable
+                search of the 10^7 grid, 6-D descent to convergence, the dense kernel's rate on a
+                stated candidate cut, the 10^8 grid's search, RANSAC (roofline_ransac) and the plane
+                fit's moment pass (roofline_hbm), 64 lock-step descents.
+  c3_strong (N > 1)  a step of the 100 x 10^6-point, 10^7-candidate grid cut over the N ranks.
+The arg-min exchange of every step goes through the library's own RCCL collective
+(ccal_comm_create + ccal_argmin_allgather, csrc/comm.hip), in a world of one rank too;
+torch.distributed only launches the ranks, hands rank 0's communicator id to the others and
+takes the maximum of the step times.
 """
 import argparse
 import json
@@ -54,29 +63,35 @@ KERNEL_NAME = {"bf16x3": "residual_bf16x3_kernel", "f32": "residual_mfma_kernel"
 KERNEL_KIND = {"bf16x3": 0, "f32": 1, "bf16x3wide": 2, "bf16x3n8": 3}
 # VALU instructions the part kernel of the exact path executes per (pose, point), from the
 # SQ_INSTS_VALU counter of the committed PMC pass (profiles/): the unit of the GD leg's roofline
-EXACT_VALU_PER_POINT_FILE = os.path.join(ROOT, "profiles", "r2_pmc_split_chain_kernel.json")
+EXACT_VALU_PER_POINT_FILE = os.path.join(ROOT, "profiles", "r3_pmc_split_chain_kernel.json")
+RESIDUAL_PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_residual_kernel.json")
+PEAK_HBM_GBS = 8000.0             # MI355X HBM3E
 
 
-def quoted_counter(path, key):
+def quoted_counter(path, key, kernel_key):
+    """(value, note): a derived counter of a committed PMC record, or (None, why) when the record is
+    missing or was measured on other kernel sources than the ones in this tree."""
+    from cameracalibration_amd.provenance import kernel_source_sha
     try:
-        return json.load(open(path))["derived"][key]
+        rec = json.load(open(path))
+        v = rec["derived"][key]
     except Exception:
-        return None
+        return None, "no record"
+    want = kernel_source_sha(kernel_key)
+    if rec.get("kernel_source_sha") != want:
+        return None, (f"stale: profiled on kernel sources {rec.get('kernel_source_sha')}, this tree has {want}")
+    return v, "profiles/" + os.path.basename(path) + f" (kernel sources {want})"
 
 
 def hbm_traffic_per_launch(args):
     """HBM bytes per launch of the residual kernel, QUOTED from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as the MI355X guide prescribes for gfx950, plus WRITE_SIZE): counters are
-    collected in their own runs (tools/profile_r2.sh), never inside the benchmark, so the figure is
-    given only for the workload it was measured on, with its source; otherwise null."""
+    collected in their own runs (tools/profile_r3.sh), never inside the benchmark, so the figure is
+    given only for the workload it was measured on and only while the kernel's sources are the
+    profiled ones; otherwise null, with the reason."""
     if (args.workload, args.clouds, args.points, args.axis, args.kernel) != ("c2", 20, 300_000, 10, "bf16x3"):
-        return None, None
-    for name in ("r2_pmc_residual_kernel.json", "r1_pmc_residual_kernel.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        v = quoted_counter(path, "hbm_traffic_bytes_per_launch")
-        if v is not None:
-            return v, "profiles/" + name
-    return None, None
+        return None, "not the profiled workload"
+    return quoted_counter(RESIDUAL_PMC_FILE, "hbm_traffic_bytes_per_launch", "residual")
 
 
 def parse():
@@ -100,10 +115,100 @@ def parse():
                     help="how the timed step scores the grid (value and roofline are only reported for dense)")
     ap.add_argument("--f32-steps", type=int, default=3,
                     help="untimed steps of the FP32-input MFMA kernel for roofline_f32 (0 = skip)")
+    ap.add_argument("--north-star", type=int, default=1,
+                    help="N = 1: the 100 x 10^6-point configurations on this GPU after the benchmark (0 = skip)")
+    ap.add_argument("--c3-steps", type=int, default=1,
+                    help="N > 1: timed dense steps of the strong-scaled 10^7-candidate grid after the benchmark (0 = skip)")
+    ap.add_argument("--c3-shard", default="",
+                    help="R/W: rehearse on one GPU the c3_strong leg of rank R in a world of W ranks")
     a = ap.parse_args()
     if a.workload == "c3":
         a.clouds, a.points = 100, 1_000_000
     return a
+
+
+def north_star(cc, opt, scene, grid3, upload_s, args):
+    """The 100 poses x 10^6 points configurations on ONE GPU (the sequence of the reference's main,
+    src/camera_calibration_optimization.cpp:576-578: discrete search, then the 6-D descent), with the
+    search done by the separable pass; the dense kernel's sustained rate is measured on a stated cut of
+    the same grid around the winner."""
+    import torch
+    o = {"workload": f"synthetic 100 poses x 1000000 pts/cloud ({scene.n_points} points), grid {grid3.size} candidates",
+         "upload_s": upload_s, "upload_GBps": scene.n_points * 12 / upload_s / 1e9}
+    opt.set_search_mode(1)
+    opt.grid_search(scene.pose_init, grid3)                         # first call: buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, cost, pose, st = opt.grid_search(scene.pose_init, grid3)
+    t1 = time.perf_counter()
+    g = cc.GdOptions.default()
+    if args.gd_iterations > 0:
+        g.max_iterations = args.gd_iterations
+    r = opt.gradient_descent(pose, g)
+    t2 = time.perf_counter()
+    o["separable_search_s"] = t1 - t0
+    o["gradient_descent_s"] = t2 - t1
+    o["time_to_converged_s"] = t2 - t0
+    o["best_index"], o["best_cost"] = idx, cost
+    o["gd"] = {"iterations": r.iterations, "converged": r.converged, "fval": r.fval, "evals": r.n_evals,
+               "iteration_cap": g.max_iterations, "ms_per_iteration": (t2 - t1) * 1e3 / max(r.iterations, 1),
+               "pose_error_vs_truth": (r.xval - scene.pose_true).tolist()}
+    # the dense kernel on a cut of 2*10^5 consecutive candidates that holds the winner
+    cut = 200_000
+    b = max(0, min(grid3.size - cut, idx - cut // 2))
+    opt.set_search_mode(0)
+    i_d, c_d, _, st_d = opt.grid_search(scene.pose_init, grid3, b, b + cut)
+    o["dense_cut"] = {"candidates": [b, b + cut], "residuals": st_d.residuals, "kernel_ms": st_d.kernel_ms,
+                      "residuals_per_s": st_d.residuals / (st_d.kernel_ms * 1e-3),
+                      "same_winner": bool((i_d, c_d) == (idx, cost)),
+                      "whole_grid_would_take_s": grid3.size * scene.n_points / (st_d.residuals / (st_d.kernel_ms * 1e-3))}
+    # BASELINE configs[3]'s grid (10^8 candidates) on this one GPU, separable pass
+    counts4 = [20, 20, 25, 20, 20, 25]
+    grid4 = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (c - 1) for c in counts4[:3]] + [10.0 / (c - 1) for c in counts4[3:]], counts4)
+    opt.set_search_mode(1)
+    t0 = time.perf_counter()
+    i4, c4, _, _ = opt.grid_search(scene.pose_init, grid4)
+    o["c4_grid_separable_search_s"] = time.perf_counter() - t0
+    o["c4_grid"] = {"candidates": grid4.size, "best_index": i4, "best_cost": c4}
+    opt.set_search_mode(0)
+    # BASELINE configs[4]: RANSAC 4096 hypotheses x 10^8 points, the plane fit's moment pass, 64 descents
+    opt.set_profiling(True)
+    opt.ransac_plane(scene.pose_true, 4096, 0.01, 7, which=cc.CCAL_DOWNSAMPLED)       # first call: buffers
+    opt.fit_plane(scene.pose_true, which=cc.CCAL_DOWNSAMPLED)
+    opt.profile(reset=True)
+    t0 = time.perf_counter()
+    plane, inl, win = opt.ransac_plane(scene.pose_true, 4096, 0.01, 7, which=cc.CCAL_DOWNSAMPLED)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        fit = opt.fit_plane(scene.pose_true, which=cc.CCAL_DOWNSAMPLED)
+    t2 = time.perf_counter()
+    pr = opt.profile()
+    opt.set_profiling(False)
+    rate = pr.ransac_tests / (pr.ransac_score_ms * 1e-3)
+    o["roofline_ransac"] = {
+        "bound": "mfma", "kernel": "inlier_mfma_kernel", "kernel_avg_ms": pr.ransac_score_ms / max(pr.ransac_calls, 1),
+        "tests_per_s": rate, "flop_per_test": 8, "achieved": rate * 8 / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "frac": rate * 8 / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+        "pipe": "FP32-input matrix instruction (16x16x4): one (hypothesis, point) test = one K=4 contraction, "
+                "two threshold compares on the vector unit",
+        "call_s": t1 - t0, "hypotheses": 4096, "inliers": inl, "winner": win,
+        "exact_recount": {"hypotheses": int(pr.ransac_recounted), "kernel_ms": pr.ransac_recount_ms},
+        "plane_error_vs_truth": (np.asarray(plane, dtype=np.float64) - scene.plane.astype(np.float64)).tolist()}
+    bytes_per_s = pr.moments_points * 12 / (pr.moments_ms * 1e-3)
+    o["roofline_hbm"] = {
+        "bound": "hbm", "kernel": "moments_kernel", "kernel_avg_ms": pr.moments_ms / max(pr.moments_calls, 1),
+        "bytes_per_point": 12, "achieved": bytes_per_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+        "frac": bytes_per_s / 1e9 / PEAK_HBM_GBS, "traffic": None, "call_s": (t2 - t1) / 5,
+        "plane_error_vs_truth": (np.asarray(fit, dtype=np.float64) - scene.plane.astype(np.float64)).tolist()}
+    rng = np.random.default_rng(1)
+    starts = scene.pose_true + rng.uniform(-1, 1, (64, 6)) * np.array([0.01] * 3 + [0.04] * 3)
+    g2 = cc.GdOptions.default()
+    g2.max_iterations = 10
+    t0 = time.perf_counter()
+    rs = opt.gradient_descent(starts, g2)
+    o["multi_start_gd"] = {"starts": 64, "iteration_cap": 10, "seconds": time.perf_counter() - t0,
+                           "best_fval": min(x.fval for x in rs), "evals": int(sum(x.n_evals for x in rs))}
+    return o
 
 
 def main():
@@ -124,18 +229,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # CCAL_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer GPUs
-    # than ranks (ranks then share devices); the real runs use RCCL ("nccl").
+    # torch.distributed is the control plane only (rendezvous, barriers, the maximum of the step times)
+    # and runs over gloo on the host; the data path's one collective is the library's own RCCL
+    # all-gather (below).  CCAL_BENCH_BACKEND=gloo rehearses the N>1 code path on a box with fewer
+    # GPUs than ranks: the ranks then share devices, which RCCL refuses, so the exchange falls back to
+    # torch's all_gather and the line says so.
     backend = os.environ.get("CCAL_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
-    xdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    xdev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     def barrier():
         if world > 1:
@@ -171,16 +276,49 @@ def main():
 
     from cameracalibration_amd.distributed import merge_argmin
 
+    # The one exchange of the path is the library's own: ccal_comm_create + ccal_argmin_allgather
+    # (ncclAllGather of 16-byte records on the context's stream).  torch.distributed only carries rank
+    # 0's communicator id to the other ranks.  The gloo rehearsal (ranks sharing one GPU, which RCCL
+    # refuses) falls back to torch's all_gather and says so in the line.
+    exchange = {"through": None, "rccl_ranks": None, "us": []}
+
+    def join_library_comm(o):
+        uid = cc.comm_unique_id() if rank == 0 else bytes(128)
+        if world > 1:
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=xdev)
+            dist.broadcast(t, 0)
+            uid = bytes(t.cpu().tolist())
+        o.comm_create(world, rank, uid)
+        n, r = o.comm_info()
+        if (n, r) != (world, rank):
+            raise SystemExit(f"RCCL reports rank {r} of {n}, the launcher {rank} of {world}")
+        return n
+
+    if backend == "nccl":
+        exchange["rccl_ranks"] = join_library_comm(opt)
+        exchange["through"] = "libccal: ccal_argmin_allgather (ncclAllGather of 16-byte records, csrc/comm.hip)"
+    else:
+        exchange["through"] = "torch.distributed all_gather over gloo (rehearsal: NOT the product's collective)"
+    exchange["control_plane"] = "torch.distributed over gloo (id broadcast, barriers, max of step times)" if world > 1 else None
+
+    def merge(o, cost, idx):
+        t0 = time.perf_counter()
+        if backend == "nccl":
+            cost, idx, _ = o.argmin_allgather(cost, idx)
+        elif world > 1:
+            cost, idx, _ = merge_argmin(cost, idx, device=xdev)
+        exchange["us"].append((time.perf_counter() - t0) * 1e6)
+        return cost, idx
+
     def step():
         idx, cost, pose, st = opt.grid_search(scene.pose_init, grid, begin, end)
-        if world > 1:
-            # the one exchange of the path: (cost, index) records over RCCL, lexicographic min
-            cost, idx, _ = merge_argmin(cost, idx, device=xdev)
-            pose = cc.grid_pose(grid, scene.pose_init, idx)
+        cost, idx = merge(opt, cost, idx)
+        pose = cc.grid_pose(grid, scene.pose_init, idx) if idx >= 0 else pose
         return idx, cost, pose, st
 
     for _ in range(args.warmup):
         step()
+    exchange["us"].clear()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
@@ -253,6 +391,11 @@ def main():
             "search": args.search,
             "parallelism": f"candidate shards x{world}, RCCL all-gather argmin" if world > 1 else "single GPU",
         },
+        # the arg-min exchange inside every timed step (a world of one rank at N = 1)
+        "exchange": {"through": exchange["through"], "rccl_ranks": exchange["rccl_ranks"],
+                     "us_per_step_rank0": float(np.mean(exchange["us"])) if exchange["us"] else None,
+                     "us_max_rank0": float(np.max(exchange["us"])) if exchange["us"] else None,
+                     "control_plane": exchange["control_plane"]},
         "value_note": None if args.search == "dense" else
                       "separable search: candidates x points per second as if every residual were evaluated; none is "
                       "(one histogram pass per rotation answers all its translations) -- not the metric, no roofline",
@@ -319,10 +462,12 @@ def main():
             # the same descent once more with device timers on: roofline of the exact path's part kernel
             opt.set_profiling(True)
             opt.profile(reset=True)
+            t_p0 = time.perf_counter()
             r_p = opt.gradient_descent(pose2, o)
+            t_p1 = time.perf_counter()
             pr = opt.profile()
             opt.set_profiling(False)
-            vpp = quoted_counter(EXACT_VALU_PER_POINT_FILE, "valu_instructions_per_pose_point")
+            vpp, vpp_source = quoted_counter(EXACT_VALU_PER_POINT_FILE, "valu_instructions_per_pose_point", "split_chain")
             if pr.split_chain_ms > 0:
                 rate = pr.split_pose_points / (pr.split_chain_ms * 1e-3)
                 out["roofline_gd"] = {
@@ -333,14 +478,23 @@ def main():
                     "pose_points_per_s": rate,
                     "us_per_pose": pr.split_chain_ms * 1e3 / (pr.split_pose_points / scene.n_points),
                     "valu_instructions_per_pose_point": vpp,
-                    "valu_source": "profiles/" + os.path.basename(EXACT_VALU_PER_POINT_FILE) if vpp else None,
+                    "valu_source": vpp_source,
                     "achieved": rate * vpp / 1e12 if vpp else None,
                     "peak": PEAK_FP64_LANE_OPS / 1e12,
                     "unit": "T lane-instructions/s (FP64-rate VALU: 16 lanes per SIMD and cycle)",
                     "frac": rate * vpp / PEAK_FP64_LANE_OPS if vpp else None,
                     "traffic": None,
                     "other_kernels_ms": {"split_finish_kernel": pr.split_finish_ms, "exact_chain_kernel": pr.whole_chain_ms,
-                                         "screen_cost_kernel+reduce": pr.screen_ms},
+                                         "screen_prep+cost+reduce": pr.screen_ms},
+                    # where an iteration's wall time goes (this profiled descent): device time of the
+                    # kernels, host time before and after the stream waits, and the waits themselves
+                    "us_per_iteration": {
+                        "wall": (t_p1 - t_p0) * 1e6 / max(r_p.iterations, 1),
+                        "split_chain_kernel": pr.split_chain_ms * 1e3 / max(r_p.iterations, 1),
+                        "split_finish_kernel": pr.split_finish_ms * 1e3 / max(r_p.iterations, 1),
+                        "screening_kernels": pr.screen_ms * 1e3 / max(r_p.iterations, 1),
+                        "host_outside_waits": (pr.exact_host_ms + pr.screen_host_ms) * 1e3 / max(r_p.iterations, 1),
+                        "waits": (pr.exact_wait_ms + pr.screen_wait_ms) * 1e3 / max(r_p.iterations, 1)},
                     "same_iterates": bool(np.array_equal(r_p.xval, r.xval) and r_p.iterations == r.iterations),
                 }
             out["time_to_converged_s"] = t3 - t1
@@ -381,9 +535,81 @@ def main():
             fast = opt.get_error_fast(np.stack([cc.grid_pose(grid, scene.pose_init, i) for i in range(nc)]))
             out["fast_vs_cpu_max_rel_err"] = float(np.max(np.abs(fast - costs) / costs))
 
+    # ---- beyond the metric's configuration: the 100 x 10^6-point cases ---------------------------
+    shard = None
+    if args.c3_shard:
+        shard = tuple(int(v) for v in args.c3_shard.split("/"))
+    if args.workload == "c2" and ((world == 1 and rank == 0 and (args.north_star or shard)) or (world > 1 and args.c3_steps > 0)):
+        opt.comm_destroy()
+        opt.close()
+        del scene
+        big = make_scene(100, 1_000_000)
+        opt3 = cc.Optimizer(dev_index)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        opt3.upload_clouds(cc.CCAL_DOWNSAMPLED, big.clouds, big.base_T_flange)
+        upload_s = time.perf_counter() - t1
+        opt3.set_plane(big.plane)
+        opt3.set_fast_kernel(KERNEL_KIND[args.kernel])
+        counts3 = [20, 20, 25, 10, 10, 10]
+        grid3 = cc.Grid.make([-20] * 3 + [-5] * 3, [40.0 / (c - 1) for c in counts3[:3]] + [10.0 / (c - 1) for c in counts3[3:]],
+                             counts3)
+        if world > 1 or shard:
+            # BASELINE configs[2]: ONE 10^7-candidate grid cut into contiguous shards, strong scaling
+            w3, r3 = (world, rank) if world > 1 else (shard[1], shard[0])
+            b3, e3 = (grid3.size * r3) // w3, (grid3.size * (r3 + 1)) // w3
+            if backend == "nccl":
+                join_library_comm(opt3)
+
+            def step3(mode):
+                opt3.set_search_mode(mode)
+                i3, c3, _, st3 = opt3.grid_search(big.pose_init, grid3, b3, e3)
+                c3, i3 = merge(opt3, c3, i3)
+                return i3, c3, st3
+
+            leg = {}
+            for mode, name, n_steps, n_warm in ((1, "separable", 3, 1), (0, "dense", args.c3_steps, 0)):
+                if n_steps <= 0:
+                    continue
+                for _ in range(n_warm):
+                    step3(mode)
+                barrier()
+                t1 = time.perf_counter()
+                k_ms = res3 = 0.0
+                for _ in range(n_steps):
+                    i3, c3, st3 = step3(mode)
+                    k_ms += st3.kernel_ms
+                    res3 += st3.residuals
+                barrier()
+                dt = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([dt], dtype=torch.float64, device=xdev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt = float(t.item())
+                leg[name] = {"steps": n_steps, "ms_per_step": dt / n_steps * 1e3, "best_index": i3, "best_cost": c3,
+                             "residuals_per_s_whole_job": float(grid3.size) * big.n_points * n_steps / dt}
+                if mode == 0:
+                    leg[name]["kernel_residuals_per_s_this_rank"] = res3 / (k_ms * 1e-3) if k_ms > 0 else None
+            leg["same_winner"] = bool("dense" not in leg or "separable" not in leg or
+                                      (leg["dense"]["best_index"], leg["dense"]["best_cost"]) ==
+                                      (leg["separable"]["best_index"], leg["separable"]["best_cost"]))
+            out["c3_strong"] = {
+                "workload": f"synthetic 100 poses x 1000000 pts/cloud, one {grid3.size}-candidate grid in {w3} contiguous shards",
+                "scaling": "strong", "ranks": w3, "rehearsed_rank": None if world > 1 else r3,
+                "candidates_this_rank": e3 - b3, "upload_s": upload_s, **leg,
+                "note": "dense: every (candidate, point) residual evaluated; separable: one histogram pass per "
+                        "rotation (same winner), reported as if every residual were evaluated"}
+            opt3.comm_destroy()
+        else:
+            out["north_star_1gpu"] = north_star(cc, opt3, big, grid3, upload_s, args)
+        opt3.close()
+
     if rank == 0:
         print(json.dumps(out), flush=True)
-    opt.close()
+    try:
+        opt.close()
+    except Exception:
+        pass
     if world > 1:
         dist.destroy_process_group()
 

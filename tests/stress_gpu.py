@@ -1,6 +1,8 @@
-"""Randomised GPU-vs-oracle stress run (not collected by pytest; run it by hand on a GPU box):
+"""Randomised GPU-vs-oracle stress run.  By hand on a GPU box, for as long as wanted:
 
     python tests/stress_gpu.py [seconds] [seed] [exact|search|gd|ingest]
+
+and, as a bounded fixed-seed slice, under pytest -m gpu (tests/test_gpu_stress_slice.py).
 
 Draws scenes, poses, planes, grids and optimiser options at random -- sizes around the kernels'
 run/segment/pass boundaries, coordinate scales over many decades, special values -- and checks the
@@ -244,6 +246,37 @@ def check_ingest(opt, rng, stats):
             print("MISMATCH ransac", s.n_points, n_hyp, thr, seed, got, want, got_inl, want_inl, flush=True)
 
 
+def one_round(opt, rng, stats, only=""):
+    u = rng.random()
+    if only:
+        {"exact": check_exact, "search": check_search, "gd": check_gd, "ingest": check_ingest}[only](opt, rng, stats)
+    elif u < 0.35:
+        check_exact(opt, rng, stats)
+    elif u < 0.6:
+        check_search(opt, rng, stats)
+    elif u < 0.8:
+        check_gd(opt, rng, stats)
+    else:
+        check_ingest(opt, rng, stats)
+
+
+def run_rounds(rounds, seed):
+    """A fixed number of rounds from a fixed seed (what tests/test_gpu_stress_slice.py runs): the same
+    scenes and checks on every run.  Returns the statistics; stats["bad"] counts mismatches."""
+    rng = np.random.default_rng(seed)
+    O.lib()
+    stats = {"exact": 0, "search": 0, "gd": 0, "ingest": 0, "bad": 0}
+    old = np.seterr(all="ignore")
+    opt = cc.Optimizer(0)
+    try:
+        for _ in range(rounds):
+            one_round(opt, rng, stats)
+    finally:
+        opt.close()
+        np.seterr(**old)
+    return stats
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
@@ -256,17 +289,7 @@ def main():
     last = t0
     np.seterr(all="ignore")
     while time.time() - t0 < seconds:
-        u = rng.random()
-        if only:
-            {"exact": check_exact, "search": check_search, "gd": check_gd, "ingest": check_ingest}[only](opt, rng, stats)
-        elif u < 0.35:
-            check_exact(opt, rng, stats)
-        elif u < 0.6:
-            check_search(opt, rng, stats)
-        elif u < 0.8:
-            check_gd(opt, rng, stats)
-        else:
-            check_ingest(opt, rng, stats)
+        one_round(opt, rng, stats, only)
         if time.time() - last > 20:
             last = time.time()
             print("progress", stats, flush=True)
