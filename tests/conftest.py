@@ -23,6 +23,14 @@ def calib1():
 
 
 @pytest.fixture(scope="session")
+def calib1_raw():
+    """The four raw clouds of the reference's example/calib_1 (z <= 0.8) with the oracle's plane and
+    raw error report (tests/golden/make_golden_raw.py)."""
+    z = np.load(os.path.join(GOLDEN, "calib1_raw.npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
 def synthetic_golden():
     return json.load(open(os.path.join(GOLDEN, "synthetic.json")))
 

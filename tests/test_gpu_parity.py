@@ -598,6 +598,38 @@ def test_fit_plane_matches_oracle(gpu_opt, oracle, calib1):
     np.testing.assert_allclose(got, want, rtol=0, atol=1.5e-8)
 
 
+def test_calib1_at_full_raw_size(gpu_opt, calib1, calib1_raw):
+    """The reference's example/calib_1 at its full size on the GPU: the plane fit over all 862 392 raw
+    points (:240-277; both entry points), the raw pass of printError (:379-405, per-cloud mean and
+    maximum, at the initial pose and at the descent's result), the device voxel grid (:196-205) and the
+    per-point report -- against the record the oracle made from the same clouds."""
+    raw = [calib1_raw["raw_%d" % k] for k in range(4)]
+    B, plane = calib1["base_T_flange"], calib1_raw["plane_full"]
+    gpu_opt.upload_clouds(1, raw, B)
+    got = gpu_opt.fit_plane(calib1["pose_init"], which=1)
+    # the same minimiser through another factorisation (normal equations here, QR in the oracle)
+    np.testing.assert_allclose(got, plane, rtol=0, atol=1.5e-8)
+    assert np.array_equal(gpu_opt.fit_plane_static(calib1["pose_init"], which=1), got)
+    gpu_opt.set_plane(plane)
+    for pose, tag in ((calib1["pose_init"], "init"), (calib1["gd6_x"], "gd6")):
+        cost, mean, mx = gpu_opt.per_cloud_error(pose, which=1)
+        assert np.array_equal(mean, calib1_raw["raw_mean_" + tag])
+        assert np.array_equal(mx, calib1_raw["raw_max_" + tag])
+        assert cost == float(calib1_raw["raw_cost_" + tag])
+        assert gpu_opt.get_error(pose[None, :], which=1)[0] == cost        # the path without the maximum
+        dist, cls = gpu_opt.point_errors(pose, which=1)
+        off = np.concatenate([[0], np.cumsum([len(c) for c in raw])])
+        for j in range(4):
+            assert dist[off[j]:off[j + 1]].max() == mx[j]
+        assert np.array_equal(cls, np.digitize(dist * 1000.0, [2.5, 5.0, 10.0]).astype(np.uint8))
+    sizes = gpu_opt.downsample_raw(0.02)
+    for k in range(4):
+        assert sizes[k] == len(calib1["ds_%d" % k])
+        assert np.array_equal(gpu_opt.download_cloud(0, k), calib1["ds_%d" % k])
+    # and the objective on the set the device made equals the committed one
+    assert gpu_opt.get_error(calib1["pose_init"][None, :])[0] == float(calib1["cost_init"])
+
+
 @pytest.mark.parametrize("outliers", [0.0, 0.3])
 def test_ransac_plane_matches_oracle(gpu_opt, oracle, outliers):
     s = make_scene(5, 6000, seed=31, ragged=True, noise=0.002)

@@ -232,3 +232,20 @@ def test_numpy_restatement_agrees_with_c_oracle(oracle, calib1):
     for pose in (s.pose_init, s.pose_true):
         assert _numpy_get_error(s.clouds, s.base_T_flange, pose, s.plane, oracle.pose_to_matrix) == \
             sc.get_error(pose, s.plane)
+
+
+def test_oracle_reproduces_the_raw_calib1_fixture(oracle, calib1, calib1_raw):
+    """The oracle against the committed full-size calib_1 record (tests/golden/calib1_raw.npz): the plane
+    fitted to all 862 392 raw points (:240-277), the raw pass of printError (:379-405) and the voxel grid
+    that produced the committed downsampled clouds (:196-205)."""
+    raw = [calib1_raw["raw_%d" % k] for k in range(4)]
+    assert [len(c) for c in raw] == list(calib1["n_raw"]) and sum(len(c) for c in raw) == 862392
+    o = oracle.OracleScene(raw, calib1["base_T_flange"])
+    plane = oracle.fit_plane(o.combined_cloud(calib1["pose_init"]))
+    assert np.array_equal(plane, calib1_raw["plane_full"]) and np.array_equal(plane, calib1["plane_full"])
+    for pose, tag in ((calib1["pose_init"], "init"), (calib1["gd6_x"], "gd6")):
+        mean, mx = o.per_cloud_error(pose, plane)
+        assert np.array_equal(mean, calib1_raw["raw_mean_" + tag]) and np.array_equal(mx, calib1_raw["raw_max_" + tag])
+        assert o.get_error(pose, plane) == float(calib1_raw["raw_cost_" + tag])
+    for k, c in enumerate(raw):
+        assert np.array_equal(oracle.voxel_grid(c), calib1["ds_%d" % k])
