@@ -177,6 +177,7 @@ SIGNATURES = {
     "ccal_grid_costs": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), C.c_int64, C.c_int64, _F]),
     "ccal_grid_error_bound": (C.c_int, [_CTX, C.c_int, _D, _P(Grid), _D, _D]),
     "ccal_argmin_merge": (C.c_int, [C.c_int, _D, _P(C.c_int64)]),
+    "ccal_device_memory": (C.c_int, [_CTX, _P(C.c_size_t), _P(C.c_size_t)]),
     "ccal_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ccal_comm_create": (C.c_int, [_CTX, C.c_int, C.c_int, C.c_char_p, _P(C.c_void_p)]),
     "ccal_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -483,6 +484,12 @@ class Optimizer:
         self._check(self._lib.ccal_argmin_allgather(self._ctx, self._comm, float(cost), int(index),
                                                     C.byref(bc), C.byref(bi), C.byref(w)))
         return float(bc.value), int(bi.value), int(w.value)
+
+    def device_memory(self):
+        """(free, total) bytes of the context's GPU."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._lib.ccal_device_memory(self._ctx, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     def fit_plane(self, pose, which: int = CCAL_RAW) -> np.ndarray:
         p = np.ascontiguousarray(pose, dtype=np.float64)

@@ -192,6 +192,15 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     return CCAL_OK;
 }
 
+extern "C" int ccal_device_memory(ccal_ctx* ctx, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!ctx) return CCAL_ERR_ARG;
+    if (!free_bytes || !total_bytes) return fail(ctx, CCAL_ERR_ARG, "device_memory: null argument");
+    if (int rc = bind(ctx)) return rc;
+    CCAL_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return CCAL_OK;
+}
+
 extern "C" const char* ccal_last_error(const ccal_ctx* ctx)
 {
     return ctx ? ctx->err.c_str() : "null context";

@@ -348,9 +348,11 @@ static int run_separable(ccal_ctx* ctx, const CloudSet& cs, const double base[6]
             }
             tj[M] = (unsigned short)(4 * nt);
         }
-        // rotations per launch: bounded by the partial buffer (8 B per cloud, translation, rotation)
+        // rotations per launch: bounded by the scratch a rotation takes, per cloud 8 B per translation of
+        // the partial buffer and 12 B per bin (tc + 1 of them, however few translations the launch holds)
+        // of the wide accumulators
         const int64_t budget = (int64_t)1 << 30;
-        int64_t nr_max = budget / (8 * (int64_t)C * nt);
+        int64_t nr_max = budget / ((int64_t)C * (8 * (int64_t)nt + 12 * ((int64_t)tc + 1)));
         nr_max = std::max<int64_t>(rb, (nr_max / rb) * rb);
         auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
             hipError_t e = b.ensure(bytes);
@@ -440,7 +442,9 @@ static GridBudget grid_budget(const ccal_ctx* ctx, const CloudSet& cs, const dou
     for (int e = 0; e < 4; ++e) pl[e] = (double)ctx->plane[e];
     const double inv_norm = 1.0 / std::sqrt(pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2]);
     const double k_dense = ctx->fast_kernel == CCAL_FAST_F32 ? 2.0 + 4.0 : 2.0 + 2.0 * 34.0 + 1.0;
-    double total = 0.0;
+    // per cloud: the reference side's term, the bound on |w4| over the box, and the largest |residual| the
+    // histogram pass can meet (rotation part + constant, translation excluded)
+    std::vector<double> ex_j(C), w4max_j(C), vmax_j(C);
     for (int j = 0; j < C; ++j) {
         const double* M = mats.data() + 12 * (size_t)j;
         const double* B = cs.base_T_flange.data() + 16 * (size_t)j;
@@ -457,17 +461,29 @@ static GridBudget grid_budget(const ccal_ctx* ctx, const CloudSet& cs, const dou
             w4 += pl[r] * inv_norm * q;
             w4_slack += wgt * row * D;
         }
-        const double w4max = std::fabs(w4) + w4_slack;
+        ex_j[j] = ex;
+        w4max_j[j] = std::fabs(w4) + w4_slack;
+        vmax_j[j] = (rn * cs.radius[j] + w4max_j[j]) * (1.0 + 1e-5);
+    }
+    // The histogram pass lays out ONE fixed point for all clouds, from the largest |residual| over
+    // rotations, clouds and points it computes itself (run_separable: wn radius_j + |a|, with wn <= rn and
+    // |a| <= the bound on |w4| here).  The largest of the per-cloud bounds is at least that, so the unit
+    // charged here -- the same for every cloud -- is at least the unit the pass works in.
+    double vmax_all = 0.0;
+    for (int j = 0; j < C; ++j)
+        if (!(vmax_j[j] <= vmax_all)) vmax_all = vmax_j[j];          // a NaN sticks
+    if (separable && !(vmax_all < 1e12)) gb.separable_ok = false;
+    const double fx_unit = 1.0 / separable_fx_scale(vmax_all);
+    double total = 0.0;
+    for (int j = 0; j < C; ++j) {
+        const double rho = cs.radius_mean[j], rn = cs.rot_norm[j] * (1.0 + 1e-9);
         double budget;
         if (separable) {
             const double span = 2.0 * rn * T;
-            // largest |residual| the histogram pass can meet: rotation part + constant, translation excluded;
-            // its fixed point rounds by half a unit and takes the sign from the unrounded value (one more unit)
-            const double vmax = (rn * cs.radius[j] + w4max) * (1.0 + 1e-5);
-            if (!(vmax < 1e12)) gb.separable_ok = false;
-            budget = u24 * ex + u24 * (6.0 * rn * rho + 5.0 * w4max + span) + 3.0 / separable_fx_scale(vmax);
+            // the fixed point rounds by half a unit and takes the sign from the unrounded value (one more unit)
+            budget = u24 * ex_j[j] + u24 * (6.0 * rn * rho + 5.0 * w4max_j[j] + span) + 3.0 * fx_unit;
         } else {
-            budget = u24 * ex + k_dense * u24 * (rn * rho + w4max);
+            budget = u24 * ex_j[j] + k_dense * u24 * (rn * rho + w4max_j[j]);
         }
         total += budget;
     }
@@ -625,7 +641,7 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
 
     Events ev;
     CCAL_HIP(ctx, ev.create(2));
-    const hipEvent_t ev_begin = ev[0], ev_end = ev[1];
+    const hipEvent_t ev_begin = ev[0], ev_end = ev[1];     // ev_end: after the last re-score pass
     CCAL_HIP(ctx, hipEventRecord(ev_begin, ctx->stream));
     float* cost_local = nullptr;
     double kernel_ms = 0.0;
@@ -658,11 +674,7 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
                        recs + n_stage1);
     unsigned int n_band = 0;
     if (int rc = select(0, n_local, &n_band)) return rc;
-    CCAL_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
-
     CCAL_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float total_ms = 0.f;
-    (void)hipEventElapsedTime(&total_ms, ev_begin, ev_end);
 
     // (Non-finite fast costs are kept by the selection -- the comparison that drops a candidate is
     // false for them -- and the reference arithmetic decides: a NaN or infinite cost never passes
@@ -710,6 +722,11 @@ extern "C" int ccal_grid_search(ccal_ctx* ctx, int which, const double base_pose
     } else {
         std::memcpy(best_pose, base_pose, 6 * sizeof(double));
     }
+    // device time of the whole call: fast pass, selection (every window of it) and the exact re-scores
+    float total_ms = 0.f;
+    CCAL_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
+    CCAL_HIP(ctx, hipEventSynchronize(ev_end));
+    (void)hipEventElapsedTime(&total_ms, ev_begin, ev_end);
     if (stats) {
         stats->n_candidates = n_local;
         stats->n_rescored = n_rescored;

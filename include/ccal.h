@@ -240,6 +240,10 @@ int ccal_comm_info(const ccal_comm* comm, int* world_size, int* rank);
 int ccal_grid_error_bound(ccal_ctx* ctx, int which, const double base_pose[6], const ccal_grid* g,
                           double* abs_out, double* rel_out);
 
+/* Free and total device memory of the context's GPU in bytes (hipMemGetInfo): a diagnostic, e.g.
+ * to check that a call allocated nothing. */
+int ccal_device_memory(ccal_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+
 /* Lexicographic (cost, index) minimum over n shard results; entries with
  * index < 0 (empty shards) are skipped.  Returns the winning slot or -1. */
 int ccal_argmin_merge(int n, const double* costs, const int64_t* indices);
@@ -249,14 +253,15 @@ int ccal_argmin_merge(int n, const double* costs, const int64_t* indices);
  * :240-272: solves a*x + b*y + c = -z, returns (a,b,1,c)/|(a,b,1)| as floats. */
 int ccal_fit_plane_lsq(ccal_ctx* ctx, int which, const double pose[6], float plane_out[4]);
 
-/* ccal_fit_plane_lsq for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same inputs, same result bit for bit; the per-cloud matrices and the partial
+/* ccal_fit_plane_lsq for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code that must not disturb an allocator).  No counterpart in
+ * the reference.  Same inputs, same result bit for bit; the per-cloud matrices and the partial
  * moments of the pass's workgroups live in a static device array of the library (256 KiB per
  * GPU, held until the process ends) instead of grow-only buffers, and the call issues kernel
- * launches and one stream wait only -- no hipMalloc / hipFree / copy call.  Limit: at most 1024
- * clouds in the set (any number of points), else CCAL_ERR_CAPACITY.  All contexts of one GPU
- * share that array: calls that overlap on one GPU race. */
+ * launches and one stream wait only -- no hipMalloc / hipFree / copy call.  It does wait for
+ * the stream and read the result on the host, so it cannot itself run under stream capture.
+ * Limit: at most 1024 clouds in the set (any number of points), else CCAL_ERR_CAPACITY.  All
+ * contexts of one GPU share that array: calls that overlap on one GPU race. */
 int ccal_fit_plane_lsq_static(ccal_ctx* ctx, int which, const double pose[6], float plane_out[4]);
 
 /* RANSAC plane with the parameters of getPlane (cloud_analyzer.cpp:103-121:

@@ -243,6 +243,21 @@ def test_cli_one_process_per_gpu_exchange(tmp_path, oracle):
     assert not idfile.exists()
     p = run_cli(tmp_path, case["cfg"], env={"CCAL_WORLD_SIZE": "2", "CCAL_RANK": "0"})
     assert p.returncode != 0 and "CCAL_COMM_FILE" in p.stderr
+    # a rendezvous file left behind by an earlier job: rank 0 replaces it (the run succeeds and removes
+    # it again); another rank does not take it for its own job's -- with the job's nonce in the environment
+    # it keeps waiting for a file that carries that nonce and gives up at the deadline instead of joining
+    # a communicator nobody else will ever join
+    idfile.write_bytes(b"\x5a" * 128 + b"job-of-yesterday")
+    p = run_cli(tmp_path, case["cfg"], env={"CCAL_WORLD_SIZE": "1", "CCAL_RANK": "0", "CCAL_COMM_FILE": str(idfile),
+                                             "CCAL_COMM_NONCE": "job-of-today"})
+    assert p.returncode == 0, p.stderr
+    assert not idfile.exists()
+    idfile.write_bytes(b"\x5a" * 128 + b"job-of-yesterday")
+    p = run_cli(tmp_path, case["cfg"], env={"CCAL_WORLD_SIZE": "2", "CCAL_RANK": "1", "CCAL_LOCAL_RANK": "0",
+                                             "CCAL_COMM_FILE": str(idfile), "CCAL_COMM_NONCE": "job-of-today",
+                                             "CCAL_COMM_TIMEOUT_S": "2"})
+    assert p.returncode != 0 and "no communicator id of this job" in p.stderr
+    assert idfile.exists()                      # not this rank's to remove
 
 
 def test_cli_usage_and_errors(tmp_path):

@@ -480,6 +480,24 @@ def test_grid_error_bound_holds(gpu_opt, ccal, mode, kind):
             fast = gpu_opt.grid_costs(base, g).astype(np.float64)
             exact = gpu_opt.get_error(_grid_all(ccal, g, base))
             assert np.all(np.abs(fast - exact) <= a + r * fast), (trial, scale)
+        # one tight cloud near the origin beside a wide one far away: the separable pass lays out ONE fixed
+        # point for both (from the wide cloud's residuals), and the bound must charge the tight cloud that
+        # coarse unit too, not the fine one its own extent would allow
+        for trial in range(4):
+            tight = (rng.normal(0, 0.002, (2500, 3)) + [0.01, -0.02, 0.3]).astype(np.float32)
+            wide = (rng.normal(0, 0.8, (int(rng.integers(50, 400)), 3)) + rng.normal(0, 30.0, 3)).astype(np.float32)
+            clouds = [tight, wide] if trial % 2 == 0 else [wide, tight]
+            B = np.stack([ccal.pose_to_matrix(np.concatenate([rng.normal(0, 0.3, 3), rng.uniform(-3, 3, 3)])).reshape(16)
+                          for _ in range(2)])
+            gpu_opt.upload_clouds(0, clouds, B)
+            plane = np.concatenate([rng.normal(0, 1, 3), [rng.normal(0, 0.3)]])
+            gpu_opt.set_plane(plane)
+            base = np.concatenate([rng.normal(0, 0.05, 3), rng.uniform(-3, 3, 3)])
+            g = ccal.Grid.make([-20] * 3 + [-5] * 3, [10] * 3 + [2.5] * 3, [5, 5, 5, 4, 4, 4])
+            a, r = gpu_opt.grid_error_bound(base, g)
+            fast = gpu_opt.grid_costs(base, g).astype(np.float64)
+            exact = np.concatenate([gpu_opt.get_error(p) for p in np.array_split(_grid_all(ccal, g, base), 4)])
+            assert np.all(np.abs(fast - exact) <= a + r * fast), ("tight beside wide", trial)
     finally:
         gpu_opt.set_fast_kernel(0)
         gpu_opt.set_search_mode(0)

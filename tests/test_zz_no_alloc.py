@@ -15,10 +15,15 @@ def test_static_plane_fit_equals_plane_fit(gpu_opt, ccal):
     small = make_scene(3, 5_000, seed=42, ragged=True)
     for s in (big, small):                                   # second call: fewer clouds, fewer blocks
         gpu_opt.upload_clouds(ccal.CCAL_RAW, s.clouds, s.base_T_flange)
-        for pose in (s.pose_init, s.pose_true):
+        # the entry point comes first, on a context that has never fitted a plane: whatever it needs
+        # must already be there, and the GPU's free memory must not move across its calls
+        free0, _ = gpu_opt.device_memory()
+        got_first = [gpu_opt.fit_plane_static(pose) for pose in (s.pose_init, s.pose_true)]
+        assert gpu_opt.device_memory()[0] == free0, "ccal_fit_plane_lsq_static changed the free device memory"
+        for pose, first in zip((s.pose_init, s.pose_true), got_first):
             want = gpu_opt.fit_plane(pose)
             got = gpu_opt.fit_plane_static(pose)
-            assert got.tobytes() == want.tobytes()
+            assert got.tobytes() == want.tobytes() == first.tobytes()
             assert abs(np.linalg.norm(got[:3]) - 1.0) < 1e-6
     np.testing.assert_allclose(got, small.plane, atol=2e-3)
     # the other set of the same context, and a second context on the same GPU (same static array)
