@@ -163,6 +163,7 @@ SIGNATURES = {
     "ccal_set_search_mode": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_gd_screening": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_chain_split": (C.c_int, [_CTX, C.c_int]),
+    "ccal_set_gd_pipelining": (C.c_int, [_CTX, C.c_int]),
     "ccal_set_profiling": (C.c_int, [_CTX, C.c_int]),
     "ccal_get_profile": (C.c_int, [_CTX, _P(Profile), C.c_int]),
     "ccal_point_errors": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_int, _D, _P(C.c_ubyte)]),
@@ -329,6 +330,11 @@ class Optimizer:
         """A descent's small exact requests cut every (pose, cloud) sum into concurrently folded parts
         (default on; results are identical either way)."""
         self._check(self._lib.ccal_set_chain_split(self._ctx, 1 if on else 0))
+
+    def set_gd_pipelining(self, on: bool) -> None:
+        """A lone descent issues its next screening pass ahead of the current trial's curvature test
+        (default off: measured slower; same iterates and counts either way)."""
+        self._check(self._lib.ccal_set_gd_pipelining(self._ctx, 1 if on else 0))
 
     def set_profiling(self, on: bool) -> None:
         """HIP-event timing of the exact and screening kernels (read with ``profile()``)."""

@@ -187,6 +187,15 @@ extern "C" int ccal_destroy(ccal_ctx* ctx)
     }
     for (hipEvent_t& e : ctx->prof_ev)
         if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipStream_t& st : ctx->aux_stream)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; }
+    for (hipEvent_t& e : ctx->job_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t& e : ctx->exact_prof_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t& e : ctx->screen_prof_ev)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (ctx->screen_ev) { (void)hipEventDestroy(ctx->screen_ev); ctx->screen_ev = nullptr; }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CCAL_OK;

@@ -139,6 +139,25 @@ struct ccal_ctx {
     ccal::HostBuf exact_in, exact_out;   // pose records + planes, and per-chain results of the exact objective
     ccal::DevBuf exact_mats;             // [pose][cloud][12]: the rows of base_T_flange_j * F(pose), built on the device
     ccal::DevBuf split_maps, split_first;  // segment records and part-0 sums of the split evaluation
+    // One exact request in flight (ccal::exact_begin ... exact_wait_rest): the poses may be cut into a first
+    // and a second part whose chain kernels follow each other on the context's stream while the
+    // finishing pass of the first part runs beside the second part's chains on a stream of its own.
+    struct ExactJob {
+        bool active = false, split = false, want_max = false;
+        int which = 0, nb = 0, n_first = 0;        // n_first: poses of the first part (0: one part)
+        double host0 = 0.0, host_ms = 0.0, wait_ms = 0.0;
+    } exact_job;
+    hipStream_t aux_stream[2] = {nullptr, nullptr};       // finishing passes of the two parts
+    hipEvent_t job_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // chains of part 1 / part 2 done, results of part 1 / 2 in place
+    hipEvent_t exact_prof_ev[3] = {nullptr, nullptr, nullptr};
+    struct ScreenJob {
+        bool active = false;
+        int which = 0, nb = 0;
+        double host0 = 0.0, host_ms = 0.0;
+    } screen_job;
+    hipEvent_t screen_ev = nullptr;                        // results of the screening request in place
+    hipEvent_t screen_prof_ev[2] = {nullptr, nullptr};
+    bool gd_pipelining = false;          // a lone descent issues its next screening pass ahead of the curvature test (measured: no gain)
     bool chain_split = true;             // small exact requests cut every chain into parts
     int64_t split_resummed = 0, split_segments = 0;   // statistics of the split evaluations
     int split_skip = 0, split_penalty = 1;            // ccal_eval: calls to go without splitting after a bad one
@@ -249,10 +268,24 @@ hipError_t download_array(ccal_ctx* ctx, void* dst, const void* src, size_t byte
 int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
                double* cost, double* per_cloud_mean, double* per_cloud_max, bool allow_split = false);
 
+// The same request in pieces (at most 4096 poses, one request in flight per context): exact_begin
+// enqueues everything and returns; with 0 < n_first < n_poses the values of the first n_first poses
+// can be collected (exact_wait_first) while the rest is still being computed, and work enqueued on the
+// context's stream in between runs beside the last finishing pass.  exact_wait_rest collects the
+// remaining values (all of them when the request was not cut) and ends the request.
+int exact_begin(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4, int n_first,
+                bool want_max, bool allow_split);
+int exact_wait_first(ccal_ctx* ctx, double* cost);
+int exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, double* per_cloud_max);
+
 // Folded FP32 objective of n poses (planes4: per-pose planes, or null for the context's plane)
 // with a bound on its distance from eval_exact's value: |cost[i] - exact cost of pose i| <=
 // bound[i] whenever both are finite (bound[i] is infinite if the set holds a non-finite point).
 int eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
                 double* cost, double* bound);
+// The same in two steps (at most 1024 poses, one request in flight): enqueue on the context's stream,
+// collect later.
+int screen_begin(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4);
+int screen_wait(ccal_ctx* ctx, double* cost, double* bound);
 
 } // namespace ccal

@@ -79,6 +79,11 @@ struct Machine {
     int64_t n_main_hits = 0;
     bool ride_along = true;   // off for the rest of a line search whose curvature test has failed once
     int chains_per_pose = 0, round_chains = 0;   // set for a single descent: clouds, compute units
+    // Set on a COPY of a machine that looks ahead: the curvature test of the trial whose gradient points are
+    // still being evaluated is taken to pass (it has, on every trial measured), so that the next iteration's
+    // screening request can be issued early.  The original machine runs the test for real afterwards and
+    // the look-ahead is kept only if both arrive at the same state.
+    bool assume_curvature_passes = false;
 
     int stencil() const { return 1 + 2 * D; }
 
@@ -286,7 +291,7 @@ struct Machine {
     // iteration ends or the next trial is set up (phase TRIAL_F).  Returns true if the iteration ended.
     bool conclude_trial(const double* g)
     {
-        const bool wolfe = dot(grad, g, D) <= o.wolfe_c2 * gg;
+        const bool wolfe = assume_curvature_passes || dot(grad, g, D) <= o.wolfe_c2 * gg;
         ++ls_it;
         ++n_trials;
         n_evals += stencil();
@@ -423,6 +428,18 @@ struct Machine {
         }
     }
 
+    // Everything the next request and its interpretation depend on.
+    bool same_state(const Machine& m) const
+    {
+        return phase == m.phase && it == m.it && ls_it == m.ls_it && last_trials == m.last_trials &&
+               first_request == m.first_request && ride_along == m.ride_along && fg_trials == m.fg_trials &&
+               std::memcmp(x, m.x, sizeof x) == 0 && std::memcmp(grad, m.grad, sizeof grad) == 0 &&
+               std::memcmp(step, m.step, sizeof step) == 0 && std::memcmp(xn, m.xn, sizeof xn) == 0 &&
+               std::memcmp(&fval, &m.fval, sizeof fval) == 0 && std::memcmp(&gg, &m.gg, sizeof gg) == 0 &&
+               std::memcmp(&alpha, &m.alpha, sizeof alpha) == 0 && std::memcmp(&grad_len, &m.grad_len, sizeof grad_len) == 0 &&
+               std::memcmp(&step_len, &m.step_len, sizeof step_len) == 0;
+    }
+
     void result(ccal_gd_result* r) const
     {
         r->iterations = it;
@@ -518,7 +535,89 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
     };
     double t_screen = 0.0, t_exact = 0.0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int64_t n_lookahead = 0, n_lookahead_kept = 0;
+    // points (dim doubles each) -> the pose / plane arrays the objective takes
+    auto to_poses = [&](const std::vector<double>& p, size_t n, std::vector<double>& po, std::vector<double>& pl) {
+        po.resize(n * 6);
+        if (dim == 10) {
+            pl.resize(n * 4);
+            for (size_t i = 0; i < n; ++i) {
+                std::memcpy(&po[i * 6], &p[i * 10], 6 * sizeof(double));
+                std::memcpy(&pl[i * 4], &p[i * 10 + 6], 4 * sizeof(double));
+            }
+        } else {
+            std::memcpy(po.data(), p.data(), n * 6 * sizeof(double));
+        }
+    };
+    std::vector<double> pts2, poses2, planes2, fs, bs, f_order;
     for (;;) {
+        // A lone descent whose next request is "the undecided centres, the expected trial's gradient points
+        // and the next main stencil" sends it in two parts: centres and next stencil first, gradient points
+        // second.  With the first part's values a copy of the machine looks ahead (curvature test taken to
+        // pass) and the next iteration's screening request goes onto the device while the second part is
+        // still being computed; it runs beside that part's finishing pass.  The machine itself then gets
+        // the whole request as before and the look-ahead counts only if it arrives where the copy is.
+        Machine& m0 = ms[0];
+        if (n_starts == 1 && ctx->gd_pipelining && m0.screening && m0.phase == Machine::TRIAL_FG && m0.ride_along) {
+            const int D = m0.D, nc = m0.fg_trials, n = m0.request_points();     // nc centres, 2 D gradient points, 1 + 2 D stencil
+            pts.resize((size_t)n * dim);
+            m0.emit(pts.data());
+            // request order: centres, next main stencil, gradient points
+            pts2.resize(pts.size());
+            std::memcpy(pts2.data(), pts.data(), (size_t)nc * dim * sizeof(double));
+            std::memcpy(pts2.data() + (size_t)nc * dim, pts.data() + (size_t)(nc + 2 * D) * dim, (size_t)(1 + 2 * D) * dim * sizeof(double));
+            std::memcpy(pts2.data() + (size_t)(nc + 1 + 2 * D) * dim, pts.data() + (size_t)nc * dim, (size_t)2 * D * dim * sizeof(double));
+            to_poses(pts2, (size_t)n, poses, planes);
+            const int n_first = nc + 1 + 2 * D;
+            f.resize(n);
+            f_order.assign(n, 0.0);
+            double t0 = now();
+            if (int rc = ccal::exact_begin(ctx, which, n, poses.data(), dim == 10 ? planes.data() : nullptr, n_first, false, true))
+                return rc;
+            bool two_parts = ctx->exact_job.n_first == n_first, looked_ahead = false;
+            Machine ahead = m0;
+            if (two_parts) {
+                if (int rc = ccal::exact_wait_first(ctx, f.data())) return rc;
+                t_exact += now() - t0;
+                // the machine's order: centres, gradient points (unknown yet: zeros), stencil
+                std::memcpy(f_order.data(), f.data(), (size_t)nc * sizeof(double));
+                std::memcpy(f_order.data() + nc + 2 * D, f.data() + nc, (size_t)(1 + 2 * D) * sizeof(double));
+                ahead.assume_curvature_passes = true;
+                ahead.feed(f_order.data());
+                ahead.assume_curvature_passes = false;
+                if (ahead.phase == Machine::SCREEN && ahead.it == m0.it + 1) {
+                    const int ns = ahead.request_points();
+                    pts.resize((size_t)ns * dim);
+                    ahead.emit(pts.data());
+                    to_poses(pts, (size_t)ns, poses2, planes2);
+                    t0 = now();
+                    if (int rc = ccal::screen_begin(ctx, which, ns, poses2.data(), dim == 10 ? planes2.data() : nullptr)) return rc;
+                    t_screen += now() - t0;
+                    looked_ahead = true;
+                    ++n_lookahead;
+                }
+                t0 = now();
+            }
+            if (int rc = ccal::exact_wait_rest(ctx, f.data() + (two_parts ? n_first : 0), nullptr, nullptr)) return rc;
+            t_exact += now() - t0;
+            std::memcpy(f_order.data(), f.data(), (size_t)nc * sizeof(double));
+            std::memcpy(f_order.data() + nc, f.data() + n_first, (size_t)2 * D * sizeof(double));
+            std::memcpy(f_order.data() + nc + 2 * D, f.data() + nc, (size_t)(1 + 2 * D) * sizeof(double));
+            m0.feed(f_order.data());
+            if (looked_ahead) {
+                const int ns = ahead.request_points();
+                fs.resize(ns);
+                bs.resize(ns);
+                t0 = now();
+                if (int rc = ccal::screen_wait(ctx, fs.data(), bs.data())) return rc;
+                t_screen += now() - t0;
+                if (m0.same_state(ahead)) {
+                    ++n_lookahead_kept;
+                    m0.feed_screen(fs.data(), bs.data());
+                }
+            }
+            continue;
+        }
         bool any = false;
         if (const size_t n = gather(true)) {
             any = true;
@@ -529,6 +628,8 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             t_screen += now() - t0;
             if (rc != CCAL_OK) return rc;
             for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed_screen(f.data() + offs[a], bound.data() + offs[a]);
+            // a lone descent's settling request goes out in two parts (top of the loop)
+            if (n_starts == 1 && ctx->gd_pipelining && ms[0].phase == Machine::TRIAL_FG && ms[0].ride_along) continue;
         }
         if (const size_t n = gather(false)) {
             any = true;
@@ -545,6 +646,9 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         std::fprintf(stderr, "gd: %.3f s in screening calls, %.3f s in exact calls; split evaluations summed %lld of %lld "
                      "segments twice (context totals)\n", t_screen, t_exact, (long long)ctx->split_resummed,
                      (long long)ctx->split_segments);
+    if (std::getenv("CCAL_GD_STATS"))
+        std::fprintf(stderr, "gd: %lld screening requests issued ahead of the curvature test, %lld of them kept\n",
+                     (long long)n_lookahead, (long long)n_lookahead_kept);
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
             std::fprintf(stderr, "gd[%d]: %lld evaluations of the sequential algorithm, %lld evaluated in %lld requests; %lld trials, "

@@ -326,6 +326,17 @@ int  ccal_set_gd_screening(ccal_ctx* ctx, int on);
  * suggests, and a short pass applies them to the true running sum, summing again whatever the
  * guess did not fit.  Same values on or off (the ordered sum of :305 either way). */
 int  ccal_set_chain_split(ccal_ctx* ctx, int on);
+/* Look-ahead of a lone descent (off by default; on != 0 enables).  The request that settles a line
+ * search -- the undecided trial centres, the expected trial's gradient points, the next iterate's
+ * stencil -- is computed in two parts, and as soon as the centres and the stencil are known the next
+ * iteration's screening pass is issued on the assumption that the trial's curvature test (:433's
+ * WolfeBacktracking) will pass; it runs on the device beside the tail of the current request.  The
+ * test is then made with the real gradient, and the early screening result is used only if the
+ * descent is where the look-ahead assumed.  Same iterates, counts and values on or off.  Measured on
+ * MI355X it does not pay: what the overlap saves (the screening pass and its host round trip, about
+ * 50 us per iteration) the two chain launches of a request cut in two lose again (two launch tails
+ * and the finishing waves sharing the chip with the second launch), so it stays off. */
+int  ccal_set_gd_pipelining(ccal_ctx* ctx, int on);
 
 /* Device-time counters of the exact and screening passes, the plane fits and the point report (off
  * by default; HIP events on the context's stream around the kernels).  The reference times host code with its TIC/TOC macros

@@ -154,6 +154,7 @@ def check_gd(opt, rng, stats):
     opt.set_plane(s.plane)
     opt.set_gd_screening(bool(rng.random() < 0.85))
     opt.set_chain_split(bool(rng.random() < 0.85))
+    opt.set_gd_pipelining(bool(rng.random() < 0.5))
     o = O.OracleScene(s.clouds, s.base_T_flange)
     go, oo = cc.GdOptions.default(), O.gd_default_opts()
     it = int(rng.integers(1, 4 if wild else 12))

@@ -887,6 +887,40 @@ def test_gradient_descent_screening_changes_nothing(gpu_opt, oracle):
     assert (r.iterations, r.n_evals, r.fval) == (w.iterations, w.n_evals, w.fval)
 
 
+@pytest.mark.parametrize("tweak", ["default", "curvature_rarely", "curvature_never"])
+def test_gradient_descent_lookahead_changes_nothing(gpu_opt, oracle, tweak):
+    """The next iteration's screening pass issued ahead of the current trial's curvature test (a switch
+    of a lone descent, off by default) gives the iterates, counts and values of a descent that does one thing after the
+    other and of the oracle -- also with options under which the curvature test fails after Armijo has
+    passed, i.e. when the look-ahead has to be thrown away -- in 6-D and 10-D."""
+    import cameracalibration_amd as cc
+    s = make_scene(4, 20000, seed=23, ragged=True)
+    upload(gpu_opt, s)
+    go, oo = cc.GdOptions.default(), oracle.gd_default_opts()
+    for opts in (go, oo):
+        opts.max_iterations = 25
+        if tweak == "curvature_rarely":
+            opts.wolfe_c2 = 0.2
+            opts.wolfe_min_step = 1e-6
+        elif tweak == "curvature_never":
+            opts.wolfe_c2 = -1.0
+            opts.wolfe_min_step = 1e-4
+    o = oracle.OracleScene(s.clouds, s.base_T_flange)
+    for x0 in (s.pose_init, np.concatenate([s.pose_init, s.plane.astype(np.float64)])):
+        res = []
+        for on in (True, False):
+            gpu_opt.set_gd_pipelining(on)
+            res.append(gpu_opt.gradient_descent(x0, go))
+        gpu_opt.set_gd_pipelining(False)
+        np.testing.assert_array_equal(res[0].xval, res[1].xval)
+        assert (res[0].iterations, res[0].converged, res[0].n_evals, res[0].fval) == \
+               (res[1].iterations, res[1].converged, res[1].n_evals, res[1].fval)
+        if len(x0) == 6:
+            w = o.gd_minimize(s.plane, x0, oo)
+            np.testing.assert_array_equal(res[0].xval, np.array(w.xval[:6]))
+            assert (res[0].iterations, res[0].n_evals, res[0].fval) == (w.iterations, w.n_evals, w.fval)
+
+
 def test_gradient_descent_chain_split_changes_nothing(gpu_opt, oracle):
     """Every (pose, cloud) sum cut into concurrently folded parts (the default for a descent's requests)
     gives the bits of the one-workgroup sum: clouds from one segment to several hundred, ragged, with
