@@ -5,6 +5,7 @@
 #pragma once
 
 #include "kernels_common.hpp"
+#include "bf16x3_split.hpp"
 
 #pragma clang fp contract(off)
 
@@ -130,15 +131,32 @@ __global__ __launch_bounds__(1024) void moments_finalize_kernel(const double* __
     }
 }
 
-// Same contraction, counting instead of summing (RANSAC scoring).  The FP32 residual of a point
-// lies within a known distance e of the reference-arithmetic one (the caller derives e per cloud),
-// so two counts bracket the reference's inlier count of a hypothesis: points with |w.p| < thr - e
+// The residual contraction of the search, counting instead of summing (RANSAC scoring).  The FP32 residual
+// of a point lies within a known distance e of the reference-arithmetic one (the caller derives e per
+// cloud), so two counts bracket the reference's inlier count of a hypothesis: points with |w.p| < thr - e
 // are inliers for certain, points with |w.p| >= thr + e are not.  thr_tab[cloud] = (thr - e, thr + e),
 // rounded outwards.  partial[0][split][candidate] = certain, partial[1][split][candidate] = possible.
 // Padding points have residual 0 and are counted wherever 0 lies below the bound; the host
 // subtracts them.  Lane counters are 32 bits wide: a lane sees 1/16 of a split's points.
+//
+// The contraction runs on the bf16 matrix pipe with both FP32 operands as exact three-way bf16 splits
+// (bf16x3_split.hpp), as in residual_bf16x3_kernel: the matrix instruction then issues in the shadow of
+// the sixteen compare / add-carry instructions that each result costs, which bound the kernel either way
+// (with the FP32-input instruction, which shares the vector unit's issue port, the two added up:
+// 74.6 ms per 4096 hypotheses x 10^8 points).
 template <int NA>
-__global__ __launch_bounds__(256) void inlier_mfma_kernel(
+__device__ inline void count_brackets(const f32x4& d, float tlo, float thi, unsigned int (&lo)[4], unsigned int (&hi)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float m = __builtin_fabsf(d[r]);
+        lo[r] += (m < tlo) ? 1u : 0u;
+        hi[r] += (m < thi) ? 1u : 0u;
+    }
+}
+
+template <int NA>
+__global__ __launch_bounds__(256, 2) void inlier_mfma_kernel(
     const float* __restrict__ W, const f32x4* __restrict__ groups,
     const int* __restrict__ group_off, unsigned long long* __restrict__ partial,
     const f32x2* __restrict__ thr_tab, int n_clouds, int n_ctiles, int n_splits)
@@ -148,6 +166,8 @@ __global__ __launch_bounds__(256) void inlier_mfma_kernel(
     const int ctile0 = (blockIdx.x * 4 + wave) * NA;
     const int split = blockIdx.y;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    constexpr int kBurst = 4;
+    static_assert(NA % kBurst == 0, "candidate tiles per wave must be a multiple of the burst");
 
     unsigned int lo[NA][4], hi[NA][4];
 #pragma unroll
@@ -163,31 +183,50 @@ __global__ __launch_bounds__(256) void inlier_mfma_kernel(
         if (gb >= ge) continue;
         const f32x2 t = thr_tab[j];
         const float tlo = t[0], thi = t[1];
-        float A[NA];
+        bf16x8 A[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
-            A[a] = W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane];
+            A[a] = split_candidate_operand(W[((int64_t)j * n_ctiles + ctile0 + a) * 64 + lane], lane >= 48);
         const f32x4* gp = groups + (int64_t)gb * 64 + lane;
         f32x4 b = gp[0];
+        bf16x8 Bc = split_point_operand(b[0]);
+        // Bursts: kBurst matrix instructions back to back, then the counting of the previous burst's results
+        // (long landed by then); the bf16 split of the next point tile rides along.  The last burst of a
+        // group is carried into the next trip; the carry starts at +infinity, which no bound lies above.
+        const float inf = __builtin_inff();
+        f32x4 carry[kBurst];
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) carry[q] = f32x4{inf, inf, inf, inf};
         for (int g = gb; g < ge; ++g) {
             f32x4 bn = b;
             if (g + 1 < ge) bn = gp[64];
             gp += 64;
+            f32x4 d[4 * NA];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                const bf16x8 Bn = split_point_operand(u < 3 ? b[u + 1] : bn[0]);
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(A[a], b[u], zero, 0, 0, 0);
+                for (int i0 = u * NA; i0 < (u + 1) * NA; i0 += kBurst) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float m = __builtin_fabsf(d[r]);
-                        lo[a][r] += (m < tlo) ? 1u : 0u;
-                        hi[a][r] += (m < thi) ? 1u : 0u;
+                    for (int q = 0; q < kBurst; ++q)
+                        d[i0 + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[(i0 + q) % NA], Bc, zero, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, kBurst, 0);
+#pragma unroll
+                    for (int q = 0; q < kBurst; ++q) {
+                        const f32x4 done = i0 == 0 ? carry[q] : d[i0 == 0 ? 0 : i0 - kBurst + q];
+                        const int a = (i0 + 4 * NA - kBurst + q) % NA;
+                        count_brackets<NA>(done, tlo, thi, lo[a], hi[a]);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 16 * kBurst + 5, 0);
                 }
+                Bc = Bn;
             }
+#pragma unroll
+            for (int q = 0; q < kBurst; ++q) carry[q] = d[4 * NA - kBurst + q];
             b = bn;
         }
+#pragma unroll
+        for (int q = 0; q < kBurst; ++q) count_brackets<NA>(carry[q], tlo, thi, lo[NA - kBurst + q], hi[NA - kBurst + q]);
     }
     const int64_t plane = (int64_t)n_splits * n_ctiles * 16;
     unsigned long long* out = partial + (int64_t)split * n_ctiles * 16;

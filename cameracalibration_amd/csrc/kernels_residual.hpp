@@ -5,6 +5,7 @@
 #pragma once
 
 #include "kernels_common.hpp"
+#include "bf16x3_split.hpp"
 
 #pragma clang fp contract(off)
 
@@ -230,38 +231,7 @@ __global__ __launch_bounds__(256, 3) void residual_mfma_kernel(
 // Measured error per residual 1.5e-9 (FP32 fmaf chain: 0.8e-9) on calib_1-like data.
 // The splits are done in registers from the same FP32 layouts the FP32 kernel
 // reads (9 VALU ops per 16-point tile and wave, shared by NA MFMAs).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ inline void split_bf16x3(float v, unsigned& h, unsigned& m, unsigned& l)
-{
-    h = __float_as_uint(v) & 0xffff0000u;             // truncation keeps every piece exact
-    const float r1 = v - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m);
-    l = __float_as_uint(r2);      // what is left has at most 8 significant bits: already a bf16 value
-}
-
-// two bf16 given as FP32 bit patterns with zero low halves: low 16 bits = a, high = b
-__device__ inline unsigned pack_bf16(unsigned a, unsigned b) { return (a >> 16) | b; }
-
-__device__ inline bf16x8 split_point_operand(float v)
-{
-    unsigned h, m, l;
-    split_bf16x3(v, h, m, l);
-    const u32x4 r = {pack_bf16(h, m), pack_bf16(h, l), pack_bf16(m, h), pack_bf16(l, m)};
-    return __builtin_bit_cast(bf16x8, r);
-}
-
-__device__ inline bf16x8 split_candidate_operand(float w, bool constant_group)
-{
-    unsigned h, m, l;
-    split_bf16x3(w, h, m, l);
-    u32x4 r;
-    if (constant_group) r = u32x4{pack_bf16(h, 0u), pack_bf16(m, 0u), pack_bf16(0u, l), 0u};
-    else r = u32x4{pack_bf16(h, h), pack_bf16(m, h), pack_bf16(m, l), pack_bf16(m, l)};
-    return __builtin_bit_cast(bf16x8, r);
-}
+// (split_bf16x3, split_point_operand, split_candidate_operand: bf16x3_split.hpp)
 
 // Promotes the FP32 lane accumulators of a wave into NA/4 FP64 totals per lane.
 // acc[a][r] of lane l belongs to candidate (l>>4)*4 + r of tile a and point column

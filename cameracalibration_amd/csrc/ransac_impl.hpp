@@ -96,9 +96,11 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
     // approximate r = (n.(M p) + d) / |n|.  Per cloud j, with u = 2^-24, c the cloud's centre,
     // rho the largest |p - c|, rn >= |R|_2 (R the 3x3 part of M), m = |M (c,1)|, Q = m + rn rho >= |M p|:
     //   reference:  every coordinate of M p rounded to float, |n_r|/|n| <= 1:           u Q
-    //   fast path:  w and p - c rounded to float, four fused multiply-adds on magnitudes of at
-    //               most |w123| |p - c| + |w4|, |w123| <= rn, |w4| = |r(c)| <= m + |d|/|n|:
-    //                                                                  6 u (rn rho + m + |d|/|n|)
+    //   fast path:  w and p - c rounded to float (2u); the contraction on the bf16 matrix pipe: products
+    //               of bf16 pairs are exact, its 32 (+2) FP32 accumulation steps are budgeted at one ulp
+    //               (2u) each, truncation included, the dropped low*low term at u -- all on magnitudes
+    //               of at most |w123| |p - c| + |w4|, |w123| <= rn, |w4| = |r(c)| <= m + |d|/|n|:
+    //                                                                  71 u (rn rho + m + |d|/|n|)
     // A hypothesis passes through a transformed point of the set, so |d|/|n| <= max_j Q_j.  The
     // FP64 arithmetic on either side stays below 2^-45 of these magnitudes; the slack covers it.
     // The matrix pipe may flush denormal operands and results: an absolute 1e-30 covers that.
@@ -122,7 +124,7 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
     int64_t n_pad_lo = 0;
     for (int j = 0; j < C; ++j) {
         const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
-        double e = kSlack * u24 * (Q[j] + 6.0 * (rn * cs.radius[j] + mj[j] + Qmax)) + 1e-30;
+        double e = kSlack * u24 * (Q[j] + 71.0 * (rn * cs.radius[j] + mj[j] + Qmax)) + 1e-30;
         if (!(e >= 0.0) || !std::isfinite(e)) e = std::numeric_limits<double>::infinity();
         // outward rounding to float, one more step for the conversion itself
         float lo = (float)((double)threshold - e), hi = (float)((double)threshold + e);

@@ -16,15 +16,15 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 
 # kernel key (tools/summarize_pmc.py) -> the headers that hold the kernel and everything it inlines
 KERNEL_SOURCES = {
-    "residual": ("kernels_residual.hpp", "kernels_common.hpp", "pose_math.hpp"),
-    "residual_f32": ("kernels_residual.hpp", "kernels_common.hpp", "pose_math.hpp"),
+    "residual": ("kernels_residual.hpp", "bf16x3_split.hpp", "kernels_common.hpp", "pose_math.hpp"),
+    "residual_f32": ("kernels_residual.hpp", "bf16x3_split.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "separable": ("kernels_separable.hpp", "kernels_common.hpp"),
     "split_chain": ("kernels_exact.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "split_finish": ("kernels_exact.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "screen": ("kernels_exact.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "point_error": ("kernels_exact.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "moments": ("kernels_fit.hpp", "kernels_common.hpp", "pose_math.hpp"),
-    "inlier": ("kernels_fit.hpp", "kernels_common.hpp", "pose_math.hpp"),
+    "inlier": ("kernels_fit.hpp", "bf16x3_split.hpp", "kernels_common.hpp", "pose_math.hpp"),
     "exact_count": ("kernels_fit.hpp", "kernels_common.hpp", "pose_math.hpp"),
 }
 
