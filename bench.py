@@ -187,10 +187,15 @@ def north_star(cc, opt, scene, grid3, upload_s, args):
     rate = pr.ransac_tests / (pr.ransac_score_ms * 1e-3)
     o["roofline_ransac"] = {
         "bound": "mfma", "kernel": "inlier_mfma_kernel", "kernel_avg_ms": pr.ransac_score_ms / max(pr.ransac_calls, 1),
-        "tests_per_s": rate, "flop_per_test": 8, "achieved": rate * 8 / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-        "frac": rate * 8 / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
-        "pipe": "FP32-input matrix instruction (16x16x4): one (hypothesis, point) test = one K=4 contraction, "
-                "two threshold compares on the vector unit",
+        "tests_per_s": rate, "flop_per_test": MATRIX_FLOP_PER_RESIDUAL["bf16x3"],
+        "achieved": rate * MATRIX_FLOP_PER_RESIDUAL["bf16x3"] / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": rate * MATRIX_FLOP_PER_RESIDUAL["bf16x3"] / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+        "pipe": "dense bf16 matrix pipe (operands as exact three-way bf16 splits, as the residual kernel); one "
+                "(hypothesis, point) test = one K=4 contraction and two threshold compares; the compares and "
+                "add-with-carries on the vector unit (16 per matrix instruction) set the pace, not the pipe",
+        # the yardstick of the task: 8 algorithmic FLOP per test against the FP32 (vector = FP32-input matrix) peak
+        "algorithmic_fp32": {"flop_per_test": FLOP_PER_RESIDUAL, "achieved": rate * FLOP_PER_RESIDUAL / 1e12,
+                             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "ratio": rate * FLOP_PER_RESIDUAL / 1e12 / PEAK_FP32_TFLOPS},
         "call_s": t1 - t0, "hypotheses": 4096, "inliers": inl, "winner": win,
         "exact_recount": {"hypotheses": int(pr.ransac_recounted), "kernel_ms": pr.ransac_recount_ms},
         "plane_error_vs_truth": (np.asarray(plane, dtype=np.float64) - scene.plane.astype(np.float64)).tolist()}

@@ -243,22 +243,6 @@ __global__ __launch_bounds__(64) void pose_table_kernel(const double* __restrict
     for (int e = 0; e < 12; ++e) mats[(int64_t)i * 12 + e] = M[e];
 }
 
-// a / b, correctly rounded, for b with a precomputed y = RN(1/b): two
-// Newton corrections with exact FMA residuals.  After the first, q1 is a
-// faithful rounding of a/b; with y within half an ulp of 1/b the second then
-// lands on RN(a/b) (Markstein, "Computation of elementary functions on the IBM
-// RISC System/6000 processor", 1990, theorem on q' = RN(q + r*y)).  The residuals
-// are exact only away from underflow and overflow, so callers take this path for
-// b in [2^-300, 2^300] and a zero or in [2^-600, 2^600] and divide otherwise.
-__device__ inline double divide_by_known(double a, double b, double y)
-{
-    const double q0 = a * y;
-    const double r0 = __builtin_fma(-b, q0, a);
-    const double q1 = __builtin_fma(r0, y, q0);
-    const double r1 = __builtin_fma(-b, q1, a);
-    return __builtin_fma(r1, y, q1);
-}
-
 // |a*qx + b*qy + c*qz + d| of exact_distance, before the division by the norm.
 __device__ inline double exact_numerator(const double* M, const double* pl, float x, float y, float z)
 {

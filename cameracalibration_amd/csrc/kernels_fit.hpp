@@ -353,36 +353,75 @@ __global__ __launch_bounds__(256) void wgen_planes_kernel(const double* __restri
     }
 }
 
-// Exact inlier counts for PB hypotheses (reference-arithmetic distance < thr).
+// Exact inlier counts for PB hypotheses (reference-arithmetic distance < thr, the strict compare of a
+// sequential scan).  The point is carried to the base frame once (src/helpers.hpp:139-151, rounded to
+// float) and measured against every plane; the division by the norm is the correctly rounded one either
+// way -- by the precomputed reciprocal where its corrections are exact (divide_by_known: plane rows carry
+// the norm, its rounded reciprocal and a flag for the norm's range), by the divider elsewhere.
 template <int PB>
 __global__ __launch_bounds__(256) void exact_count_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
-    const BlockDesc* __restrict__ blocks, const double* __restrict__ mats,
-    const double* __restrict__ planes /* PB x kPlaneStride */, double thr,
+    const BlockDesc* __restrict__ blocks, int n_blocks, const double* __restrict__ mats,
+    const double* __restrict__ planes /* PB x kPlaneStride */, int n_planes /* <= PB in use */, double thr,
     unsigned long long* __restrict__ counts)
 {
     __shared__ double sM[12];
     __shared__ double sP[PB * kPlaneStride];
-    const BlockDesc bd = blocks[blockIdx.x];
-    if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+    __shared__ unsigned int sC[4][PB];
     for (int i = threadIdx.x; i < PB * kPlaneStride; i += blockDim.x) sP[i] = planes[i];
-    __syncthreads();
+    constexpr unsigned kLo = 0x1a700000u, kHi = 0x65700000u;   // high words of 2^-600, 2^600
+    // a workgroup walks a contiguous share of the block table and adds its counts to the totals once:
+    // with one workgroup per block, every wave's sixteen atomic adds landed on the same two cache lines
+    // and the pass took 10 ms for 10^8 points, ten times what its arithmetic needs
+    const int b0 = (int)(((int64_t)n_blocks * blockIdx.x) / gridDim.x), b1 = (int)(((int64_t)n_blocks * (blockIdx.x + 1)) / gridDim.x);
     unsigned int cnt[PB];
 #pragma unroll
     for (int k = 0; k < PB; ++k) cnt[k] = 0;
-    for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
-        const float x = xs[i], y = ys[i], z = zs[i];
+    int cloud = -1;
+    for (int b = b0; b < b1; ++b) {
+        const BlockDesc bd = blocks[b];
+        if (bd.cloud != cloud) {                      // uniform: the next cloud's matrix
+            __syncthreads();
+            if (threadIdx.x < 12) sM[threadIdx.x] = mats[(int64_t)bd.cloud * 12 + threadIdx.x];
+            __syncthreads();
+            cloud = bd.cloud;
+        }
+        for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
+            const double xd = (double)xs[i], yd = (double)ys[i], zd = (double)zs[i];
+            double q[3];
 #pragma unroll
-        for (int k = 0; k < PB; ++k)
-            cnt[k] += exact_distance(sM, sP + k * kPlaneStride, x, y, z) < thr ? 1u : 0u;
+            for (int r = 0; r < 3; ++r) {
+                double p = sM[r * 4 + 3];
+                p = xd * sM[r * 4 + 0] + p;
+                p = yd * sM[r * 4 + 1] + p;
+                p = zd * sM[r * 4 + 2] + p;
+                q[r] = (double)(float)p;
+            }
+#pragma unroll
+            for (int k = 0; k < PB; ++k) {
+                if (k < n_planes) {                   // uniform
+                    const double* pl = sP + k * kPlaneStride;
+                    const double num = __builtin_fabs(pl[0] * q[0] + pl[1] * q[1] + pl[2] * q[2] + pl[3]);
+                    const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(num) >> 32);
+                    double d;
+                    if (__builtin_expect(pl[6] != 0.0 && hi >= kLo && hi < kHi, 1)) d = divide_by_known(num, pl[4], pl[5]);
+                    else d = num / pl[4];
+                    cnt[k] += d < thr ? 1u : 0u;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < PB; ++k) {
         unsigned int c = cnt[k];
         for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+        if ((threadIdx.x & 63) == 0) sC[threadIdx.x >> 6][k] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < PB) {
+        const unsigned int c = sC[0][threadIdx.x] + sC[1][threadIdx.x] + sC[2][threadIdx.x] + sC[3][threadIdx.x];
+        if (c) atomicAdd(&counts[threadIdx.x], (unsigned long long)c);
     }
 }
-
 
 } // namespace ccal

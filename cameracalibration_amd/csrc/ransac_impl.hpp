@@ -53,12 +53,13 @@ void jacobi3(double A[3][3], double V[3][3])
 }
 
 template <int PB>
-void launch_exact_count(ccal_ctx* ctx, const CloudSet& cs, double thr)
+void launch_exact_count(ccal_ctx* ctx, const CloudSet& cs, int n_planes, double thr)
 {
-    hipLaunchKernelGGL(exact_count_kernel<PB>, dim3(cs.n_blocks), dim3(256), 0, ctx->stream,
+    const int grid = std::min(cs.n_blocks, 8 * ctx->n_cu);
+    hipLaunchKernelGGL(exact_count_kernel<PB>, dim3(grid), dim3(256), 0, ctx->stream,
                        cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(),
-                       cs.blocks.as<BlockDesc>(), ctx->mats_buf.as<double>(),
-                       ctx->planes_buf.as<double>(), thr,
+                       cs.blocks.as<BlockDesc>(), cs.n_blocks, ctx->mats_buf.as<double>(),
+                       ctx->planes_buf.as<double>(), n_planes, thr,
                        ctx->count_buf.as<unsigned long long>());
 }
 
@@ -227,13 +228,17 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
         const int nb = (int)batch.size();
         for (int k = 0; k < kRecount; ++k) {
             const int h = batch[k < nb ? k : 0];
-            for (int e = 0; e < 5; ++e) pl[(size_t)k * kPlaneStride + e] = planes[(size_t)h * kHypStride + e];
+            double* row = pl.data() + (size_t)k * kPlaneStride;
+            for (int e = 0; e < 5; ++e) row[e] = planes[(size_t)h * kHypStride + e];
+            row[5] = 1.0 / row[4];                                        // rounded reciprocal of the norm
+            row[6] = (row[4] > 0x1p-300 && row[4] < 0x1p300) ? 1.0 : 0.0; // the range its corrections are exact in
+            row[7] = 0.0;
         }
         CCAL_HIP(ctx, hipMemcpyAsync(ctx->planes_buf.p, pl.data(), pl.size() * sizeof(double),
                                      hipMemcpyHostToDevice, ctx->stream));
         CCAL_HIP(ctx, hipMemsetAsync(ctx->count_buf.p, 0, kRecount * sizeof(unsigned long long), ctx->stream));
         if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[0], ctx->stream));
-        launch_exact_count<kRecount>(ctx, cs, (double)threshold);
+        launch_exact_count<kRecount>(ctx, cs, nb, (double)threshold);
         if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
         CCAL_HIP(ctx, hipGetLastError());
         CCAL_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->count_buf.p, kRecount * sizeof(unsigned long long),
