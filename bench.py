@@ -288,27 +288,56 @@ def main():
     exchange = {"through": None, "rccl_ranks": None, "us": []}
 
     def join_library_comm(o):
-        uid = cc.comm_unique_id() if rank == 0 else bytes(128)
+        """Collective.  Returns RCCL's own count of the communicator's ranks, or None when any rank could
+        not join (every rank then uses the fallback; the reason goes into the line)."""
+        err = ""
+        try:
+            uid = cc.comm_unique_id() if rank == 0 else bytes(128)
+        except Exception as e:                      # librccl missing on rank 0: the others must not wait in RCCL
+            uid, err = bytes(128), f"comm_unique_id: {e}"
         if world > 1:
-            t = torch.tensor(list(uid), dtype=torch.uint8, device=xdev)
+            t = torch.tensor(list(uid) + [1 if err else 0], dtype=torch.uint8, device=xdev)
             dist.broadcast(t, 0)
-            uid = bytes(t.cpu().tolist())
-        o.comm_create(world, rank, uid)
-        n, r = o.comm_info()
-        if (n, r) != (world, rank):
-            raise SystemExit(f"RCCL reports rank {r} of {n}, the launcher {rank} of {world}")
+            v = t.cpu().tolist()
+            uid = bytes(v[:128])
+            if v[128] and not err:
+                err = "rank 0 could not make a communicator id"
+        n = None
+        if not err:
+            try:
+                o.comm_create(world, rank, uid)
+                n, r = o.comm_info()
+                if (n, r) != (world, rank):
+                    err = f"RCCL reports rank {r} of {n}, the launcher {rank} of {world}"
+            except Exception as e:
+                err = f"comm_create: {e}"
+        if world > 1:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=xdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and not err:
+                err = "another rank could not join the communicator"
+        if err:
+            o.comm_destroy()
+            exchange["fallback_reason"] = err
+            return None
         return n
 
+    exchange["fallback_reason"] = None
     if backend == "nccl":
         exchange["rccl_ranks"] = join_library_comm(opt)
+    if exchange["rccl_ranks"]:
         exchange["through"] = "libccal: ccal_argmin_allgather (ncclAllGather of 16-byte records, csrc/comm.hip)"
+    elif backend == "nccl":
+        exchange["through"] = ("torch.distributed all_gather over gloo -- FALLBACK, the library's RCCL communicator "
+                               "could not be made: " + str(exchange["fallback_reason"]))
     else:
         exchange["through"] = "torch.distributed all_gather over gloo (rehearsal: NOT the product's collective)"
     exchange["control_plane"] = "torch.distributed over gloo (id broadcast, barriers, max of step times)" if world > 1 else None
+    use_library = [bool(exchange["rccl_ranks"])]
 
     def merge(o, cost, idx):
         t0 = time.perf_counter()
-        if backend == "nccl":
+        if use_library[0]:
             cost, idx, _ = o.argmin_allgather(cost, idx)
         elif world > 1:
             cost, idx, _ = merge_argmin(cost, idx, device=xdev)
@@ -563,8 +592,8 @@ def main():
             # BASELINE configs[2]: ONE 10^7-candidate grid cut into contiguous shards, strong scaling
             w3, r3 = (world, rank) if world > 1 else (shard[1], shard[0])
             b3, e3 = (grid3.size * r3) // w3, (grid3.size * (r3 + 1)) // w3
-            if backend == "nccl":
-                join_library_comm(opt3)
+            if use_library[0]:
+                use_library[0] = bool(join_library_comm(opt3))
 
             def step3(mode):
                 opt3.set_search_mode(mode)
