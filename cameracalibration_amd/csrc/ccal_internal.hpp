@@ -144,6 +144,7 @@ struct ccal_ctx {
     // finishing pass of the first part runs beside the second part's chains on a stream of its own.
     struct ExactJob {
         bool active = false, split = false, want_max = false;
+        bool watch_words = false;                  // the wait watches the result words instead of the event
         int which = 0, nb = 0, n_first = 0;        // n_first: poses of the first part (0: one part)
         double host0 = 0.0, host_ms = 0.0, wait_ms = 0.0;
     } exact_job;
@@ -151,7 +152,7 @@ struct ccal_ctx {
     hipEvent_t job_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // chains of part 1 / part 2 done, results of part 1 / 2 in place
     hipEvent_t exact_prof_ev[3] = {nullptr, nullptr, nullptr};
     struct ScreenJob {
-        bool active = false;
+        bool active = false, watch_words = false;
         int which = 0, nb = 0;
         double host0 = 0.0, host_ms = 0.0;
     } screen_job;

@@ -229,11 +229,19 @@ constexpr int kPoseRec = 9;
 
 __global__ __launch_bounds__(64) void pose_table_kernel(const double* __restrict__ recs,
                                                         const double* __restrict__ base_T_flange, int n_poses,
-                                                        int n_clouds, double* __restrict__ mats /* [pose][cloud][12] */)
+                                                        int n_clouds, double* __restrict__ mats /* [pose][cloud][12] */,
+                                                        const double* __restrict__ planes_in,
+                                                        double* __restrict__ planes_out /* [pose][kPlaneStride] */)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_poses * n_clouds) return;
     const int k = i / n_clouds, j = i % n_clouds;
+    // the planes move into device memory with the table: every workgroup of the chain kernels reads its
+    // pose's plane, and the request's copy sits in host memory
+    if (j == 0) {
+#pragma unroll
+        for (int e = 0; e < kPlaneStride; ++e) planes_out[(int64_t)k * kPlaneStride + e] = planes_in[(int64_t)k * kPlaneStride + e];
+    }
     const double* r = recs + (int64_t)k * kPoseRec;
     const double t[3] = {r[0], r[1], r[2]}, sn[3] = {r[3], r[4], r[5]}, cs[3] = {r[6], r[7], r[8]};
     double R[9], M[12];
