@@ -120,7 +120,7 @@ static int split_parts(const ccal_ctx* ctx, int64_t chains)
 }
 
 int ccal::exact_begin(ccal_ctx* ctx, int which, int nb, const double* poses6, const double* planes4, int n_first,
-                      bool want_max, bool allow_split)
+                      bool want_max, bool allow_split, const double* expected_sums)
 {
     if (int rc = check_set(ctx, which)) return rc;
     if (nb <= 0 || nb > 4096 || !poses6) return fail(ctx, CCAL_ERR_ARG, "exact_begin: 1 to 4096 poses");
@@ -137,13 +137,16 @@ int ccal::exact_begin(ccal_ctx* ctx, int which, int nb, const double* poses6, co
     // request is a few launches and a wait, with no copy call on either side.
     const size_t n_mats = (size_t)nb * C * 12, n_recs = (size_t)nb * kPoseRec, n_planes = (size_t)nb * kPlaneStride,
                  n_out = (size_t)nb * C;
-    CCAL_HIP(ctx, ctx->exact_in.ensure((n_recs + n_planes) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->exact_in.ensure((n_recs + n_planes + n_out) * sizeof(double)));
     CCAL_HIP(ctx, ctx->exact_out.ensure(2 * n_out * sizeof(double)));
-    CCAL_HIP(ctx, ctx->exact_mats.ensure((n_mats + n_planes) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->exact_mats.ensure((n_mats + n_planes + 2 * n_out) * sizeof(double)));
     double* recs = ctx->exact_in.as<double>();
     double* planes_host = recs + n_recs;
+    double* expected_host = planes_host + n_planes;
     double* mats = ctx->exact_mats.as<double>();
     double* planes = mats + n_mats;          // the device's copy, made by pose_table_kernel
+    double* guess_scale = planes + n_planes; // [pose][cloud][2], made by pose_table_kernel
+    if (expected_sums) std::memcpy(expected_host, expected_sums, n_out * sizeof(double));
     double* hsum = ctx->exact_out.as<double>();
     double* hmax = hsum + n_out;
     for (int k = 0; k < nb; ++k) {
@@ -175,11 +178,13 @@ int ccal::exact_begin(ccal_ctx* ctx, int which, int nb, const double* poses6, co
                        (int64_t)nb * cs.total_segs * (int64_t)sizeof(SegMap) <= ((int64_t)1 << 30);   // records: at most 1 GiB
     const bool prof = ctx->profiling;
     // (with profiling on the waits go through the events, whose times are what is asked for)
-    job.watch_words = split && !prof && !(n_first > 0 && n_first < nb);
+    job.watch_words = split && !prof;
     if (job.watch_words) mark_unwritten(hsum, 2 * n_out);
     hipStream_t S = ctx->stream;
     hipLaunchKernelGGL(pose_table_kernel, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, S, recs,
-                       cs.base_dev.as<double>(), nb, C, mats, planes_host, planes);
+                       cs.base_dev.as<double>(), nb, C, mats, planes_host, planes,
+                       expected_sums && cs.seg_sums_valid ? expected_host : nullptr, cs.seg_sums.as<double>(),
+                       cs.cloud_seg_off_dev.as<int64_t>(), guess_scale);
     if (prof) CCAL_HIP(ctx, hipEventRecord(ctx->exact_prof_ev[0], S));
     job.which = which;
     job.nb = nb;
@@ -194,8 +199,8 @@ int ccal::exact_begin(ccal_ctx* ctx, int which, int nb, const double* poses6, co
             hipLaunchKernelGGL(split_chain_kernel, dim3((unsigned)((int64_t)np * C * K)), dim3(64 * kSplitWaves), 0, S,
                                cs.xs.as<float>(), cs.ys.as<float>(), cs.zs.as<float>(), cs.cloud_pt_off_dev.as<int64_t>(),
                                cs.cloud_seg_off_dev.as<int64_t>(), mats + (size_t)p0 * C * 12, planes + (size_t)p0 * kPlaneStride,
-                               np, C, (int64_t)cs.total_pts, K, cs.seg_sums.as<double>(), cs.total_segs,
-                               ctx->split_maps.as<SegMap>() + (size_t)p0 * cs.total_segs,
+                               np, C, (int64_t)cs.total_pts, K, cs.seg_sums.as<double>(), guess_scale + 2 * (size_t)p0 * C,
+                               cs.total_segs, ctx->split_maps.as<SegMap>() + (size_t)p0 * cs.total_segs,
                                ctx->split_first.as<double>() + (size_t)p0 * C);
         };
         // ... and the pass that applies the parts to the true sums, one wave per chain, on `stream`
@@ -273,7 +278,14 @@ int ccal::exact_wait_first(ccal_ctx* ctx, double* cost)
     ccal_ctx::ExactJob& job = ctx->exact_job;
     if (!job.active || !job.n_first || !cost) return fail(ctx, CCAL_ERR_STATE, "exact_wait_first: no two-part request in flight");
     const double t0 = ctx->profiling ? host_ms() : 0.0;
-    CCAL_HIP(ctx, hipEventSynchronize(ctx->job_ev[2]));
+    if (job.watch_words) {
+        // the first part's words of both arrays (sums, then the counts of segments summed twice)
+        const size_t n_all = (size_t)job.nb * ctx->sets[job.which].n_clouds, n_a = (size_t)job.n_first * ctx->sets[job.which].n_clouds;
+        CCAL_HIP(ctx, wait_for_words(ctx->exact_out.as<double>(), n_a, ctx->job_ev[2]));
+        CCAL_HIP(ctx, wait_for_words(ctx->exact_out.as<double>() + n_all, n_a, ctx->job_ev[2]));
+    } else {
+        CCAL_HIP(ctx, hipEventSynchronize(ctx->job_ev[2]));
+    }
     const double t1 = ctx->profiling ? host_ms() : 0.0;
     exact_collect(ctx, 0, job.n_first, cost, nullptr, nullptr);
     if (ctx->profiling) {
@@ -292,7 +304,7 @@ int ccal::exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, d
     hipError_t e = job.watch_words
                        ? wait_for_words(ctx->exact_out.as<double>(), 2 * (size_t)job.nb * ctx->sets[job.which].n_clouds, ctx->job_ev[3])
                        : hipEventSynchronize(ctx->job_ev[3]);
-    if (e == hipSuccess && job.n_first) e = hipEventSynchronize(ctx->job_ev[2]);
+    if (e == hipSuccess && job.n_first && !job.watch_words) e = hipEventSynchronize(ctx->job_ev[2]);
     job.active = false;
     CCAL_HIP(ctx, e);
     const double t1 = prof ? host_ms() : 0.0;
@@ -316,6 +328,12 @@ int ccal::exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, d
         }
     }
     cs.seg_sums_valid = true;
+    if (!job.want_max || !job.split) {
+        // the request's last pose left its running sums behind (both kinds of kernel); its totals, for callers
+        // that want to say how far the next request's chains are from them
+        const double* hs = ctx->exact_out.as<double>() + (size_t)(job.nb - 1) * C;
+        cs.seg_ref_totals.assign(hs, hs + C);
+    }
     if (job.split) {
         const double* hmax = ctx->exact_out.as<double>() + (size_t)job.nb * C;
         for (size_t i = 0; i < (size_t)job.nb * C; ++i) ctx->split_resummed += (int64_t)hmax[i];
@@ -331,7 +349,7 @@ int ccal::exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, d
 
 int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6,
                      const double* planes4, double* cost, double* per_cloud_mean,
-                     double* per_cloud_max, bool allow_split)
+                     double* per_cloud_max, bool allow_split, const double* expected_sums)
 {
     if (int rc = check_set(ctx, which)) return rc;
     if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost)))
@@ -344,7 +362,7 @@ int ccal::eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
         const int nb = std::min(max_batch, n_poses - k0);
         if (int rc = exact_begin(ctx, which, nb, poses6 + 6 * (size_t)k0, planes4 ? planes4 + 4 * (size_t)k0 : nullptr, 0,
-                                 per_cloud_max != nullptr, allow_split))
+                                 per_cloud_max != nullptr, allow_split, expected_sums ? expected_sums + (size_t)k0 * C : nullptr))
             return rc;
         if (int rc = exact_wait_rest(ctx, cost + k0, per_cloud_mean ? per_cloud_mean + (size_t)k0 * C : nullptr,
                                      per_cloud_max ? per_cloud_max + (size_t)k0 * C : nullptr))
@@ -450,7 +468,7 @@ int ccal::screen_begin(ccal_ctx* ctx, int which, int nb, const double* poses6, c
     return CCAL_OK;
 }
 
-int ccal::screen_wait(ccal_ctx* ctx, double* cost, double* bound)
+int ccal::screen_wait(ccal_ctx* ctx, double* cost, double* bound, double* per_cloud_sums)
 {
     ccal_ctx::ScreenJob& job = ctx->screen_job;
     if (!job.active || !cost || !bound) return fail(ctx, CCAL_ERR_STATE, "screen_wait: no request in flight");
@@ -481,6 +499,7 @@ int ccal::screen_wait(ccal_ctx* ctx, double* cost, double* bound)
             f += mean;
             b += budget[(size_t)k * C + j] + (double)kScreenLaneAdds * u24 * mean;
         }
+        if (per_cloud_sums) std::memcpy(per_cloud_sums + (size_t)k * C, sums + (size_t)k * C, (size_t)C * sizeof(double));
         cost[k] = f / (double)C;
         bound[k] = std::isfinite(b) ? kScreenSlack * b / (double)C : std::numeric_limits<double>::infinity();
     }
@@ -492,7 +511,7 @@ int ccal::screen_wait(ccal_ctx* ctx, double* cost, double* bound)
 }
 
 int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
-                      double* cost, double* bound)
+                      double* cost, double* bound, double* per_cloud_sums)
 {
     if (int rc = check_set(ctx, which)) return rc;
     if (n_poses < 0 || (n_poses > 0 && (!poses6 || !cost || !bound)))
@@ -502,7 +521,9 @@ int ccal::eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses
     for (int k0 = 0; k0 < n_poses; k0 += max_batch) {
         const int nb = std::min(max_batch, n_poses - k0);
         if (int rc = screen_begin(ctx, which, nb, poses6 + 6 * (size_t)k0, planes4 ? planes4 + 4 * (size_t)k0 : nullptr)) return rc;
-        if (int rc = screen_wait(ctx, cost + k0, bound + k0)) return rc;
+        if (int rc = screen_wait(ctx, cost + k0, bound + k0,
+                                 per_cloud_sums ? per_cloud_sums + (size_t)k0 * ctx->sets[which].n_clouds : nullptr))
+            return rc;
     }
     return CCAL_OK;
 }

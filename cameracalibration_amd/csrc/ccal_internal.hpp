@@ -92,6 +92,7 @@ struct CloudSet {
     DevBuf cloud_seg_off_dev, seg_sums;
     int64_t total_segs = 0;
     bool seg_sums_valid = false;        // some evaluation since the upload has written seg_sums
+    std::vector<double> seg_ref_totals; // per cloud: the total of the chain that wrote seg_sums (host copy)
     std::vector<int> cloud_block_off;  // n_clouds + 1
     int n_blocks = 0;
 
@@ -267,26 +268,30 @@ hipError_t download_array(ccal_ctx* ctx, void* dst, const void* src, size_t byte
 // allow_split: the poses are close to those of the previous such call (a descent), so a small request
 // may cut its chains into parts whose units are guessed from that call's sums (same values either way).
 int eval_exact(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
-               double* cost, double* per_cloud_mean, double* per_cloud_max, bool allow_split = false);
+               double* cost, double* per_cloud_mean, double* per_cloud_max, bool allow_split = false,
+               const double* expected_sums = nullptr);
 
 // The same request in pieces (at most 4096 poses, one request in flight per context): exact_begin
 // enqueues everything and returns; with 0 < n_first < n_poses the values of the first n_first poses
 // can be collected (exact_wait_first) while the rest is still being computed, and work enqueued on the
 // context's stream in between runs beside the last finishing pass.  exact_wait_rest collects the
 // remaining values (all of them when the request was not cut) and ends the request.
+// expected_sums ([pose][cloud], or null): what the caller expects the chains to sum to (the screening pass's
+// sums of a nearby pose, say).  They only steer the guesses of a split request, never a value.
 int exact_begin(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4, int n_first,
-                bool want_max, bool allow_split);
+                bool want_max, bool allow_split, const double* expected_sums = nullptr);
 int exact_wait_first(ccal_ctx* ctx, double* cost);
 int exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, double* per_cloud_max);
 
 // Folded FP32 objective of n poses (planes4: per-pose planes, or null for the context's plane)
 // with a bound on its distance from eval_exact's value: |cost[i] - exact cost of pose i| <=
 // bound[i] whenever both are finite (bound[i] is infinite if the set holds a non-finite point).
+// per_cloud_sums ([pose][cloud], optional): the FP32 pass's sum of distances of every cloud.
 int eval_screen(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4,
-                double* cost, double* bound);
+                double* cost, double* bound, double* per_cloud_sums = nullptr);
 // The same in two steps (at most 1024 poses, one request in flight): enqueue on the context's stream,
 // collect later.
 int screen_begin(ccal_ctx* ctx, int which, int n_poses, const double* poses6, const double* planes4);
-int screen_wait(ccal_ctx* ctx, double* cost, double* bound);
+int screen_wait(ccal_ctx* ctx, double* cost, double* bound, double* per_cloud_sums = nullptr);
 
 } // namespace ccal

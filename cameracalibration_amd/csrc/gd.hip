@@ -46,6 +46,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -71,6 +72,7 @@ struct Machine {
     enum Phase { MAIN, SCREEN, TRIAL_F, TRIAL_FG, TRIAL_G, DONE } phase = DONE;
     bool screening = false;
     int fg_trials = 0;         // TRIAL_FG: centres in the request; the last one is the expected pass
+    int screen_first = -1;     // TRIAL_FG / TRIAL_G straight after a screening request: that request's number of the trial at xn
     int64_t n_screen_requests = 0, n_screened_fail = 0, n_screened_pass = 0, n_expected_hits = 0, n_expected_misses = 0;
     // speculation: trials per request (first request of a line search / later ones)
     int last_trials = 3;
@@ -343,6 +345,7 @@ struct Machine {
         const int n = planned_screen();
         ++n_screen_requests;
         first_request = false;
+        screen_first = -1;
         int t = 0;
         for (; t < n; ++t) {
             const double thr = fval - o.wolfe_c1 * alpha * gg;
@@ -360,6 +363,7 @@ struct Machine {
         if (std::isfinite(fast[t]) && std::isfinite(bound[t]) && fast[t] + bound[t] <= thr_t) {
             ++n_screened_pass;
             phase = TRIAL_G;                    // xn passes Armijo whatever its exact value
+            screen_first = t;
             return;
         }
         double a = alpha;
@@ -367,6 +371,7 @@ struct Machine {
             if (std::isfinite(fast[u]) && fast[u] <= fval - o.wolfe_c1 * a * gg) {
                 fg_trials = u - t + 1;
                 phase = TRIAL_FG;
+                screen_first = t;
                 return;
             }
             a = o.wolfe_decrease * a;
@@ -396,6 +401,7 @@ struct Machine {
     {
         n_requested += request_points();
         ++n_requests;
+        screen_first = -1;
         if (phase == MAIN) {
             feed_main(f);
         } else if (phase == TRIAL_G) {
@@ -549,7 +555,9 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             std::memcpy(po.data(), p.data(), n * 6 * sizeof(double));
         }
     };
-    std::vector<double> pts2, poses2, planes2, fs, bs, f_order;
+    std::vector<double> pts2, poses2, planes2, fs, bs, f_order, screen_sums, expected_sums, next_sums;
+    int64_t n_stencil_screens = 0;
+    const int n_clouds = ctx->sets[which].n_clouds;
     for (;;) {
         // A lone descent whose next request is "the undecided centres, the expected trial's gradient points
         // and the next main stencil" sends it in two parts: centres and next stencil first, gradient points
@@ -572,7 +580,16 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             f.resize(n);
             f_order.assign(n, 0.0);
             double t0 = now();
-            if (int rc = ccal::exact_begin(ctx, which, n, poses.data(), dim == 10 ? planes.data() : nullptr, n_first, false, true))
+            const double* expected = nullptr;
+            if (m0.screen_first >= 0 && (size_t)(m0.screen_first + nc) * n_clouds <= screen_sums.size()) {
+                expected_sums.resize((size_t)n * n_clouds);
+                for (int i = 0; i < n; ++i) {
+                    const int from = m0.screen_first + (i < nc ? i : nc - 1);
+                    std::memcpy(&expected_sums[(size_t)i * n_clouds], &screen_sums[(size_t)from * n_clouds], n_clouds * sizeof(double));
+                }
+                expected = expected_sums.data();
+            }
+            if (int rc = ccal::exact_begin(ctx, which, n, poses.data(), dim == 10 ? planes.data() : nullptr, n_first, false, true, expected))
                 return rc;
             bool two_parts = ctx->exact_job.n_first == n_first, looked_ahead = false;
             Machine ahead = m0;
@@ -609,7 +626,8 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
                 fs.resize(ns);
                 bs.resize(ns);
                 t0 = now();
-                if (int rc = ccal::screen_wait(ctx, fs.data(), bs.data())) return rc;
+                screen_sums.resize((size_t)ns * n_clouds);
+                if (int rc = ccal::screen_wait(ctx, fs.data(), bs.data(), screen_sums.data())) return rc;
                 t_screen += now() - t0;
                 if (m0.same_state(ahead)) {
                     ++n_lookahead_kept;
@@ -623,8 +641,11 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             any = true;
             bound.resize(n);
             const double t0 = now();
+            // a lone descent keeps the pass's per-cloud sums: the exact request that settles the line search
+            // evaluates poses at or next to these centres, and says so (see expected_sums of exact_begin)
+            if (n_starts == 1) screen_sums.resize(n * (size_t)n_clouds);
             int rc = ccal::eval_screen(ctx, which, (int)n, poses.data(), dim == 10 ? planes.data() : nullptr, f.data(),
-                                       bound.data());
+                                       bound.data(), n_starts == 1 ? screen_sums.data() : nullptr);
             t_screen += now() - t0;
             if (rc != CCAL_OK) return rc;
             for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed_screen(f.data() + offs[a], bound.data() + offs[a]);
@@ -633,9 +654,48 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         }
         if (const size_t n = gather(false)) {
             any = true;
+            const double* expected = nullptr;
+            const Machine& m = ms[0];
+            if (n_starts == 1 && m.screen_first >= 0 && (m.phase == Machine::TRIAL_FG || m.phase == Machine::TRIAL_G)) {
+                // centres: the screening pass's sums of the same pose; the gradient points and the next main
+                // stencil: those of the trial they surround or follow
+                const int nc = m.phase == Machine::TRIAL_FG ? m.fg_trials : 0;
+                const int last = m.screen_first + (nc > 0 ? nc - 1 : 0);
+                if ((size_t)(last + 1) * n_clouds <= screen_sums.size()) {
+                    expected_sums.resize(n * (size_t)n_clouds);
+                    for (size_t i = 0; i < n; ++i) {
+                        const int from = (int)i < nc ? m.screen_first + (int)i : last;
+                        std::memcpy(&expected_sums[i * n_clouds], &screen_sums[(size_t)from * n_clouds], n_clouds * sizeof(double));
+                    }
+                    expected = expected_sums.data();
+                    // The next main stencil lies a momentum term away from the trial.  While the descent still moves
+                    // far in one iteration (the totals have changed by more than 3 % since the last request) that is
+                    // too far for the trial's sums to stand in: one more pose through the screening pass (about 40 us)
+                    // saves the exact request several hundred.
+                    const std::vector<double>& ref = ctx->sets[which].seg_ref_totals;
+                    const int D = m.D;
+                    if (m.ride_along && ref.size() == (size_t)n_clouds && n >= (size_t)(1 + 2 * D)) {
+                        double moved = 0.0;
+                        for (int j = 0; j < n_clouds; ++j)
+                            if (ref[j] > 0.0) moved = std::max(moved, std::fabs(screen_sums[(size_t)last * n_clouds + j] / ref[j] - 1.0));
+                        if (moved > 0.03) {
+                            const double* centre = pts.data() + (n - (size_t)(1 + 2 * D)) * dim;    // the stencil's first point
+                            double pose1[6], plane1[4], f1, b1;
+                            std::memcpy(pose1, centre, sizeof pose1);
+                            if (dim == 10) std::memcpy(plane1, centre + 6, sizeof plane1);
+                            next_sums.resize(n_clouds);
+                            if (int rc = ccal::eval_screen(ctx, which, 1, pose1, dim == 10 ? plane1 : nullptr, &f1, &b1, next_sums.data()))
+                                return rc;
+                            ++n_stencil_screens;
+                            for (size_t i = n - (size_t)(1 + 2 * D); i < n; ++i)
+                                std::memcpy(&expected_sums[i * n_clouds], next_sums.data(), n_clouds * sizeof(double));
+                        }
+                    }
+                }
+            }
             const double t0 = now();
             int rc = ccal::eval_exact(ctx, which, (int)n, poses.data(), dim == 10 ? planes.data() : nullptr, f.data(),
-                                      nullptr, nullptr, true);
+                                      nullptr, nullptr, true, expected);
             t_exact += now() - t0;
             if (rc != CCAL_OK) return rc;
             for (size_t a = 0; a < active.size(); ++a) ms[active[a]].feed(f.data() + offs[a]);
@@ -649,6 +709,9 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
     if (std::getenv("CCAL_GD_STATS"))
         std::fprintf(stderr, "gd: %lld screening requests issued ahead of the curvature test, %lld of them kept\n",
                      (long long)n_lookahead, (long long)n_lookahead_kept);
+    if (std::getenv("CCAL_GD_STATS"))
+        std::fprintf(stderr, "gd: %lld next main points went through the screening pass ahead of their exact request\n",
+                     (long long)n_stencil_screens);
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
             std::fprintf(stderr, "gd[%d]: %lld evaluations of the sequential algorithm, %lld evaluated in %lld requests; %lld trials, "

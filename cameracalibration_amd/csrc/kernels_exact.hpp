@@ -231,11 +231,31 @@ __global__ __launch_bounds__(64) void pose_table_kernel(const double* __restrict
                                                         const double* __restrict__ base_T_flange, int n_poses,
                                                         int n_clouds, double* __restrict__ mats /* [pose][cloud][12] */,
                                                         const double* __restrict__ planes_in,
-                                                        double* __restrict__ planes_out /* [pose][kPlaneStride] */)
+                                                        double* __restrict__ planes_out /* [pose][kPlaneStride] */,
+                                                        const double* __restrict__ expected_sum /* [pose][cloud] or null */,
+                                                        const double* __restrict__ sref /* running sums of an earlier evaluation */,
+                                                        const int64_t* __restrict__ cloud_seg_off,
+                                                        double* __restrict__ guess_scale /* [pose][cloud][2]: factors for the lower and the upper end */)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_poses * n_clouds) return;
     const int k = i / n_clouds, j = i % n_clouds;
+    // What the caller expects this chain to sum to, over what the chain that left the running sums behind
+    // summed to: the part kernel scales those sums by it before it guesses its units (1 when unknown), and
+    // widens them by 1/64 either way -- by more when the totals have moved a lot, since the sums along the
+    // chain then have not all moved alike (up to 0.3: the widened ends stay within a factor of two of each
+    // other, which is as far as a record's two units reach).
+    double gs = 1.0, w = 0.015625;
+    if (expected_sum) {
+        const double q = expected_sum[i] / sref[cloud_seg_off[j + 1] - 1];    // a cloud's last entry: the chain's total
+        if (q > 0.0625 && q < 16.0) {             // a NaN fails both
+            gs = q;
+            const double moved = 0.5 * __builtin_fabs(q - 1.0);
+            w = moved > w ? (moved < 0.3 ? moved : 0.3) : w;
+        }
+    }
+    guess_scale[2 * (int64_t)i] = gs * (1.0 - w);
+    guess_scale[2 * (int64_t)i + 1] = gs * (1.0 + w);
     // the planes move into device memory with the table: every workgroup of the chain kernels reads its
     // pose's plane, and the request's copy sits in host memory
     if (j == 0) {
@@ -859,6 +879,7 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     const int64_t* __restrict__ cloud_pt_off, const int64_t* __restrict__ cloud_seg_off,
     const double* __restrict__ mats, const double* __restrict__ planes, int n_poses, int n_clouds,
     int64_t total_pts, int K, const double* __restrict__ sref /* sums at segment starts, previous evaluation */,
+    const double* __restrict__ guess_scale /* [pose][cloud][2]: what to multiply the ends of a segment's range of sref by */,
     int64_t total_segs, SegMap* __restrict__ maps /* [pose][segment] */, double* __restrict__ first_sum)
 {
     // Part-major order: consecutive workgroups go to the 8 XCDs in turn, and the workgroups of part 0
@@ -896,6 +917,8 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     const double two52 = 4503599627370496.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* ref = sref + cloud_seg_off[j];
+    // the previous evaluation's sums scaled to this chain's expected total and widened (pose_table_kernel)
+    const double widen_lo = guess_scale[2 * ((int64_t)k * n_clouds + j)], widen_hi = guess_scale[2 * ((int64_t)k * n_clouds + j) + 1];
     SegMap* out = maps + ((int64_t)k * total_segs + cloud_seg_off[j]);
     DistanceSource::Raw raw = src.fetch(b0 + (int64_t)(s_begin + wave) * kChainSeg + lane * kChainRun);
     for (int seg = s_begin + wave; seg < s_end; seg += kSplitWaves) {
@@ -911,8 +934,7 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
         if (seg + kSplitWaves < s_end) raw = src.fetch(g0 + (int64_t)kSplitWaves * kChainSeg);
         const bool past_end = g0 + kChainRun > e;     // the chain's last run(s): elements past the end count as +0.0
 
-        // the previous evaluation's sums at this segment's ends, widened by 1/64 either way
-        const double lo = ref[seg] * (1.0 - 0.015625), hi = ref[seg + 1] * (1.0 + 0.015625);
+        const double lo = ref[seg] * widen_lo, hi = ref[seg + 1] * widen_hi;
         const int eb_lo = (int)((unsigned long long)__double_as_longlong(lo) >> 52);
         const int eb_hi = (int)((unsigned long long)__double_as_longlong(hi) >> 52);
         const bool guess = eb_lo >= 64 && eb_lo <= 1999;      // sign bit set or out of range: no map
@@ -1010,6 +1032,63 @@ __global__ __launch_bounds__(64 * kSplitWaves, 5) void split_chain_kernel(
     }
 }
 
+// The sequential sum continued from s over one segment held eight elements per lane (d, in chain order;
+// `finite`: the lane's elements are ordinary non-negative numbers), by one wave and in registers only: the
+// lane-level half of chain_reduce (same units, same tests, same one-by-one additions where the sum leaves
+// its binade or is not usable), without its workgroup barriers and LDS round trips, which a lone wave
+// can only wait out.  Returns the same value in every lane.
+__device__ inline double wave_resum_segment(const double (&d)[kChainRun], bool finite, double s)
+{
+    constexpr unsigned long long kTwo53 = 1ull << 53;
+    constexpr unsigned long long kMantissa = (1ull << 52) - 1;
+    const double two52 = 4503599627370496.0;
+    const int lane = threadIdx.x & 63;
+    double run_max = d[0];
+#pragma unroll
+    for (int t = 1; t < kChainRun; ++t) run_max = max_f64(run_max, d[t]);
+    int consumed = 0;                                   // lanes whose runs are in s
+    while (consumed < 64) {
+        const unsigned long long sbits = (unsigned long long)__double_as_longlong(s);
+        const int ebiased = (int)(sbits >> 52);         // sign included
+        const bool usable = ebiased >= 64 && ebiased <= 2000;
+        if (!usable) {
+            // s is zero (or out of the range the units cover): the next run one by one
+            double sv = s;
+#pragma unroll
+            for (int t = 0; t < kChainRun; ++t) sv += d[t];
+            s = __longlong_as_double((long long)read_lane_u64((unsigned long long)__double_as_longlong(sv), consumed));
+            ++consumed;
+            continue;
+        }
+        const double scale = __longlong_as_double((long long)((unsigned long long)(2098 - ebiased) << 52));
+        const unsigned long long S = (sbits & kMantissa) | (1ull << 52);
+        unsigned long long i0 = 0, i1 = 0;              // consumed lanes: the identity
+        bool ok = true, tie = false;
+        if (lane >= consumed) {
+            ok = finite && run_max * scale < two52;
+            if (ok) chain_fold_run(d, scale, i0, i1, tie);
+        }
+        chain_scan<64>(i0, i1, lane);
+        const unsigned long long tot = (S & 1ull) ? i1 : i0;
+        const bool bad = !ok || S + tot >= kTwo53;
+        const unsigned long long mask = __ballot(bad ? 1 : 0);
+        if (!mask) {
+            const unsigned long long all = read_lane_u64(tot, 63);
+            return __longlong_as_double((long long)(((S + all) & kMantissa) | ((unsigned long long)ebiased << 52)));
+        }
+        // lane L's run leaves the binade (or cannot be folded): everything before it by the prefix, the run
+        // itself one by one
+        const int L = __builtin_ctzll(mask);
+        const unsigned long long before = L > 0 ? read_lane_u64(tot, L - 1) : 0ull;
+        double sv = __longlong_as_double((long long)(((S + before) & kMantissa) | ((unsigned long long)ebiased << 52)));
+#pragma unroll
+        for (int t = 0; t < kChainRun; ++t) sv += d[t];
+        s = __longlong_as_double((long long)read_lane_u64((unsigned long long)__double_as_longlong(sv), L));
+        consumed = L + 1;
+    }
+    return s;
+}
+
 // One wave per chain: the records of split_chain_kernel applied to the true sum (see above).
 __global__ __launch_bounds__(64) void split_finish_kernel(
     const float* __restrict__ xs, const float* __restrict__ ys, const float* __restrict__ zs,
@@ -1091,11 +1170,20 @@ __global__ __launch_bounds__(64) void split_finish_kernel(
             if (adv < nl) {
                 // this segment again, from the true sum, by the sequential routine
                 if (ref && lane == 0) ref[base + adv] = s;
-                const int64_t sb = b0 + (int64_t)(base + adv) * kChainSeg;
-                const int64_t se = sb + kChainSeg < e ? sb + kChainSeg : e;
-                double s_new, mx;
-                chain_reduce<1, false>(src, sb > b ? sb : b, se, s, s_new, mx);
-                s = s_new;
+                const int64_t sb = b0 + (int64_t)(base + adv) * kChainSeg;     // part 0 holds the chain's first segment: sb > b
+                const int64_t g0 = sb + lane * kChainRun;
+                double d[kChainRun];
+                bool finite = src.values(src.fetch(g0), d);
+                if (g0 + kChainRun > e) {
+                    // the chain's last segment: elements past the end count as +0.0
+                    finite = true;
+#pragma unroll
+                    for (int t = 0; t < kChainRun; ++t) {
+                        d[t] = g0 + t < e ? d[t] : 0.0;
+                        finite = finite && d[t] >= 0.0 && d[t] < __builtin_inf();
+                    }
+                }
+                s = wave_resum_segment(d, finite, s);
                 ++resummed;
                 cur = adv + 1;
             } else {

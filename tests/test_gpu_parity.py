@@ -184,6 +184,12 @@ def test_exact_eval_edge_shapes_and_values(gpu_opt, oracle):
     assert cost == o.get_error(pose0, zplane) and mean[0] == 0.0 and mx[1] == 3.0e7
     np.testing.assert_array_equal(mean, om)
     np.testing.assert_array_equal(mx, ox)
+    # the same scene through the chains cut into parts (every call after the first): sums that stay zero
+    # have no unit to guess, the spike's segment leaves every guess behind
+    near = pose0 + rng.normal(0, 1e-6, (4, 6))
+    want = [o.get_error(p, zplane) for p in near]
+    for _ in range(3):
+        np.testing.assert_array_equal(gpu_opt.get_error(near), want)
 
     # a NaN and an infinity among ordinary points
     bad = clouds[3].copy()
@@ -197,6 +203,11 @@ def test_exact_eval_edge_shapes_and_values(gpu_opt, oracle):
     om, _ = o.per_cloud_error(poses[1], plane)
     np.testing.assert_array_equal(mean, om)          # NaN == NaN under assert_array_equal
     assert mean[0] == om[0] and np.isnan(mean[1]) and not np.isfinite(mean[2])
+    # ... and cut into parts: the non-finite element's run is added one by one wherever it falls
+    near = poses[1] + rng.normal(0, 1e-6, (4, 6))
+    want = [o.get_error(p, plane) for p in near]
+    for _ in range(3):
+        np.testing.assert_array_equal(gpu_opt.get_error(near), want)
 
 
 def test_exact_eval_large_clouds_bit_equal(gpu_opt, oracle):

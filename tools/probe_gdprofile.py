@@ -15,6 +15,8 @@ idx, cost, pose, _ = opt.grid_search(s.pose_init, grid)
 o = cc.GdOptions.default()
 if len(sys.argv) > 1:
     o.max_iterations = int(sys.argv[1])
+if os.environ.get("PROBE_PIPELINING"):
+    opt.set_gd_pipelining(True)
 for rep in range(2):
     t = time.perf_counter(); r = opt.gradient_descent(pose, o); dt = time.perf_counter() - t
     print(f"descent: {r.iterations} iterations, {r.n_evals} evals, fval {r.fval!r}, {dt:.4f} s = {dt / max(r.iterations, 1) * 1e6:.1f} us/iteration", flush=True)
