@@ -656,6 +656,19 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
             any = true;
             const double* expected = nullptr;
             const Machine& m = ms[0];
+            if (n_starts == 1 && m.screening && m.phase == Machine::MAIN && n == (size_t)m.stencil()) {
+                // a main stencil that did not ride along with a gradient (the first of a descent, as a rule): the
+                // running sums on the device belong to some other pose, so the centre goes through the screening
+                // pass first and its sums stand in for the whole stencil
+                double f1, b1;
+                next_sums.resize(n_clouds);
+                if (int rc = ccal::eval_screen(ctx, which, 1, poses.data(), dim == 10 ? planes.data() : nullptr, &f1, &b1, next_sums.data()))
+                    return rc;
+                ++n_stencil_screens;
+                expected_sums.resize(n * (size_t)n_clouds);
+                for (size_t i = 0; i < n; ++i) std::memcpy(&expected_sums[i * n_clouds], next_sums.data(), n_clouds * sizeof(double));
+                expected = expected_sums.data();
+            }
             if (n_starts == 1 && m.screen_first >= 0 && (m.phase == Machine::TRIAL_FG || m.phase == Machine::TRIAL_G)) {
                 // centres: the screening pass's sums of the same pose; the gradient points and the next main
                 // stencil: those of the trial they surround or follow
@@ -710,7 +723,7 @@ extern "C" int ccal_gd_minimize_multi(ccal_ctx* ctx, int which, int dim, int n_s
         std::fprintf(stderr, "gd: %lld screening requests issued ahead of the curvature test, %lld of them kept\n",
                      (long long)n_lookahead, (long long)n_lookahead_kept);
     if (std::getenv("CCAL_GD_STATS"))
-        std::fprintf(stderr, "gd: %lld next main points went through the screening pass ahead of their exact request\n",
+        std::fprintf(stderr, "gd: %lld main points went through the screening pass ahead of their exact request\n",
                      (long long)n_stencil_screens);
     if (std::getenv("CCAL_GD_STATS"))
         for (int s = 0; s < n_starts; ++s)
