@@ -14,6 +14,8 @@ SHORT="python3 bench.py --steps 1 --warmup 1 --cpu-candidates 0 --f32-steps 1 --
 C5="python3 tools/probe_c5_kernels.py 100 1000000"
 echo "[profile] kernel trace of the default benchmark"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace_bench.json 2> $OUT/trace.err || { echo "trace failed"; tail -5 $OUT/trace.err; exit 1; }
+echo "[profile] kernel trace of the benchmark without its north-star leg (per-kernel averages of the C2 workload alone)"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c2 -o trace -- python3 bench.py --steps 3 --warmup 1 --cpu-candidates 0 --north-star 0 > $OUT/trace_c2_bench.json 2> $OUT/trace_c2.err || { echo "c2 trace failed"; tail -5 $OUT/trace_c2.err; exit 1; }
 echo "[profile] kernel trace of the plane-fit / point-report kernels"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_trace -o trace -- $C5 > $OUT/c5_trace.log 2> $OUT/c5_trace.err || { echo "c5 trace failed"; tail -5 $OUT/c5_trace.err; exit 1; }
 pass() {   # tag, program..., then "--", counters...
@@ -35,4 +37,6 @@ pass c5clock $C5 -- GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD TCC_HIT_sum TCC_MI
 python3 tools/summarize_pmc.py $OUT > $OUT/summary.json && echo "[profile] summary written"
 echo "[profile] ingest kernels at 100 clouds x 1e6 points (voxel grid)"
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ingest_vox -o t -- python3 tools/probe_voxel.py 100 1000000 > $OUT/ingest_vox.log 2> $OUT/ingest_vox.err || { echo "ingest voxel trace failed"; exit 1; }
+# the per-dispatch traces are large and nothing reads them afterwards: the statistics files stay
+find $OUT -name "*_kernel_trace.csv" -delete
 echo "[profile] done"

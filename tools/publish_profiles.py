@@ -12,6 +12,10 @@ dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "r3_kernel_stats.csv"))
 line = open(os.path.join(src, "trace_bench.json")).read().strip().split("\n")[-1]
 json.dump(json.loads(line), open(os.path.join(dst, "r3_bench_under_rocprof.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "trace_c2", "trace_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "trace_c2", "trace_kernel_stats.csv"), os.path.join(dst, "r3_c2_kernel_stats.csv"))
+    line = open(os.path.join(src, "trace_c2_bench.json")).read().strip().split("\n")[-1]
+    json.dump(json.loads(line), open(os.path.join(dst, "r3_c2_bench_under_rocprof.json"), "w"), indent=1)
 summary = json.load(open(os.path.join(src, "summary.json")))
 json.dump(summary, open(os.path.join(dst, "r3_pmc_summary.json"), "w"), indent=1)
 k = summary["kernels"]
