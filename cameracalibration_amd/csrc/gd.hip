@@ -36,6 +36,10 @@
 //     trial to expect to pass: the undecided centres up to it go into one exact request together
 //     with its finite-difference points and the next main stencil (two dependent device steps
 //     per iteration; the speculation is dropped when another trial passes).
+//   * a lone descent tells the exact request what it expects every chain to sum to (the screening pass's
+//     per-cloud sums of the trial; of the next main point too while the descent still moves far in one
+//     iteration): the requests' chains are cut into parts whose units are guessed from an earlier
+//     evaluation, and the guesses follow the expectation.  Expectations steer guesses, never values.
 // Values past the accepted trial are dropped.  The evaluation count reported is
 // that of the sequential algorithm (1 + 2*dim per trial it visits).
 #include "ccal_internal.hpp"
