@@ -533,8 +533,8 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     std::vector<unsigned int> radius2_bits(n_clouds, 0u);
     std::vector<size_t> rblock_off(n_clouds + 1, 0);
     for (int j = 0; j < n_clouds; ++j) rblock_off[j + 1] = rblock_off[j] + (n_pts[j] + 255) / 256;
-    std::vector<float> radius_sums(rblock_off[n_clouds], 0.f);
-    DevBuf radius_sums_dev;   // per tiling block: sum of its points' distances from the centre
+    std::vector<float> radius_sums(4 * rblock_off[n_clouds], 0.f);
+    DevBuf radius_sums_dev;   // per tiling block: sums of its points' distances from the centre and of |dx|, |dy|, |dz|
     const bool trace_upload = std::getenv("CCAL_TRACE_UPLOAD") != nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tr0 = now();
@@ -557,7 +557,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                                    src, (int64_t)n_pts[j], fast_slot_stride((int64_t)n_pts[j]), pt_off[j], (int64_t)cs.group_off[j],
                                    cs.centres_dev.as<double>() + 3 * (size_t)j, cs.xs.as<float>(), cs.ys.as<float>(),
                                    cs.zs.as<float>(), cs.groups.as<float>(), cs.radius_dev.as<unsigned int>() + j,
-                                   radius_sums_dev.as<float>() + rblock_off[j]);
+                                   radius_sums_dev.as<float>() + 4 * rblock_off[j]);
             }
         };
         if (e == hipSuccess) e = stage_clouds(ctx, n_clouds, xyz, n_pts, pt_off, stage.as<float>(), tile_batch);
@@ -607,13 +607,18 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
     // mean distance from the centre (float square roots and block sums: the factor covers their roundings)
     // and a bound on the 2-norm of the robot pose's 3x3 part: 1 for a rotation, else its Frobenius norm
     cs.radius_mean.assign(n_clouds, 0.0);
+    cs.radius_axis.assign(3 * (size_t)n_clouds, 0.0);
     cs.rot_norm.assign(n_clouds, 0.0);
     for (int j = 0; j < n_clouds; ++j) {
-        double sum = 0.0;
-        for (size_t b = rblock_off[j]; b < rblock_off[j + 1]; ++b) sum += (double)radius_sums[b];
-        cs.radius_mean[j] = std::isfinite(cs.radius[j]) && std::isfinite(sum)
-                                ? std::min(cs.radius[j], sum / (double)n_pts[j] * (1.0 + 1e-5))
-                                : std::numeric_limits<double>::infinity();
+        double sum[4] = {0.0, 0.0, 0.0, 0.0};
+        for (size_t b = rblock_off[j]; b < rblock_off[j + 1]; ++b)
+            for (int k = 0; k < 4; ++k) sum[k] += (double)radius_sums[4 * b + k];
+        auto mean_of = [&](double v) {
+            return std::isfinite(cs.radius[j]) && std::isfinite(v) ? std::min(cs.radius[j], v / (double)n_pts[j] * (1.0 + 1e-5))
+                                                                    : std::numeric_limits<double>::infinity();
+        };
+        cs.radius_mean[j] = mean_of(sum[0]);
+        for (int k = 0; k < 3; ++k) cs.radius_axis[3 * (size_t)j + k] = mean_of(sum[1 + k]);
         const double* B = base_T_flange + 16 * (size_t)j;
         double off = 0.0, fro = 0.0;
         for (int a = 0; a < 3; ++a)
@@ -627,10 +632,12 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
         if (!std::isfinite(cs.rot_norm[j])) cs.rot_norm[j] = std::numeric_limits<double>::infinity();
     }
     {
-        std::vector<double> cb(2 * (size_t)n_clouds);
+        std::vector<double> cb(kCloudBound * (size_t)n_clouds);
         for (int j = 0; j < n_clouds; ++j) {
-            cb[2 * (size_t)j] = cs.radius_mean[j];
-            cb[2 * (size_t)j + 1] = cs.rot_norm[j] * (1.0 + 1e-9);
+            double* b = &cb[kCloudBound * (size_t)j];
+            b[0] = cs.radius_mean[j];
+            b[1] = cs.rot_norm[j] * (1.0 + 1e-9);
+            for (int k = 0; k < 3; ++k) b[2 + k] = cs.radius_axis[3 * (size_t)j + k];
         }
         CCAL_HIP(ctx, cs.bound_dev.ensure(cb.size() * sizeof(double)));
         CCAL_HIP(ctx, hipMemcpy(cs.bound_dev.p, cb.data(), cb.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -644,6 +651,7 @@ extern "C" int ccal_upload_clouds(ccal_ctx* ctx, int which, int n_clouds,
                             hipMemcpyHostToDevice));
     CCAL_HIP(ctx, hipMemcpy(cs.base_dev.p, cs.base_T_flange.data(),
                             16 * (size_t)n_clouds * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = presize_request_buffers(ctx, cs)) return rc;
     cs.ready = true;
     return CCAL_OK;
 }

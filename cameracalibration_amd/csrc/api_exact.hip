@@ -106,6 +106,30 @@ static int ensure_job_objects(ccal_ctx* ctx)
     return CCAL_OK;
 }
 
+// The buffers, streams and events a descent's requests use, made when a cloud set is uploaded rather than
+// inside the first requests (pinned and device allocations cost 0.1-0.9 ms each, about 5 ms of a first
+// descent): sized for requests of up to kPresizePoses poses, grown later like any other when that is not
+// enough.  The segment records are left to the first request when they would take more than 256 MiB.
+constexpr int kPresizePoses = 48;
+
+int ccal::presize_request_buffers(ccal_ctx* ctx, const CloudSet& cs)
+{
+    if (int rc = ensure_job_objects(ctx)) return rc;
+    const size_t nb = kPresizePoses, C = (size_t)cs.n_clouds;
+    const size_t n_mats = nb * C * 12, n_recs = nb * kPoseRec, n_planes = nb * kPlaneStride, n_out = nb * C;
+    CCAL_HIP(ctx, ctx->exact_in.ensure((n_recs + n_planes + n_out) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->exact_out.ensure(2 * n_out * sizeof(double)));
+    CCAL_HIP(ctx, ctx->exact_mats.ensure((n_mats + n_planes + 2 * n_out) * sizeof(double)));
+    CCAL_HIP(ctx, ctx->split_first.ensure(n_out * sizeof(double)));
+    const size_t map_bytes = nb * (size_t)cs.total_segs * sizeof(SegMap);
+    if (map_bytes <= ((size_t)256 << 20)) CCAL_HIP(ctx, ctx->split_maps.ensure(map_bytes));
+    CCAL_HIP(ctx, ctx->screen_in.ensure(nb * kScreenRec * sizeof(double)));
+    CCAL_HIP(ctx, ctx->screen_out.ensure(2 * n_out * sizeof(double)));
+    CCAL_HIP(ctx, ctx->screen_partial.ensure((size_t)cs.n_blocks * kScreenParts * nb * sizeof(double)));
+    CCAL_HIP(ctx, ctx->screen_w.ensure(n_out * 4 * sizeof(float)));
+    return CCAL_OK;
+}
+
 // parts per chain of a split launch: enough workgroups to fill the chip several times over (measured
 // on 620 chains: 4 parts 0.578 s, 8 parts 0.562 s, 12 parts 0.560 s per descent)
 static int split_parts(const ccal_ctx* ctx, int64_t chains)
@@ -405,16 +429,15 @@ extern "C" int ccal_eval(ccal_ctx* ctx, int which, int n_poses, const double* po
 }
 
 // Error budget of the screening pass against the exact objective, per cloud and pose, with
-// rho = MEAN distance of the cloud's points from its centre c (the budgets below are per point and linear
-// in |p - c|; the objective is a mean over the points), m = |M (c,1)| (the centre carried to the base
-// frame) and w4 = the folded constant (the signed distance of the centre):
+// rho_a = MEAN of |p_a - c_a| over the cloud's points along its own axis a (the budgets below are per point
+// and linear in the |p_a - c_a|; the objective is a mean over the points), c the cloud's centre, R the 3x3
+// part of M and w4 = the folded constant (the signed distance of the centre):
 //   exact path:  rounds every transformed coordinate q_r to float (src/helpers.hpp:151), and the distance weighs
 //                coordinate r with |n_r|/|n|: the residual moves by at most
-//                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + |R|_2 |p - c|)
-//                                                                       (R = the 3x3 part of M)
+//                2^-24 sum_r |n_r|/|n| |q_r| <= 2^-24 sum_r |n_r|/|n| (|(M (c,1))_r| + sum_a |R_ra| |p_a - c_a|)
 //   fast path:   w and p - c rounded to float (one rounding each), then three fused multiply-adds (the
 //                constant is the innermost addend), each on a magnitude of at most
-//                |w123||p - c| + |w4|:  5 * 2^-24 (|w123| rho + |w4|)
+//                sum_a |w_a| |p_a - c_a| + |w4|:  5 * 2^-24 (sum_a |w_a| rho_a + |w4|)
 //   sums:        8 + 6 FP32 adds per partial (eight points per lane, six levels of the wave reduction):
 //                kScreenLaneAdds * 2^-24 of the cloud's mean residual
 // The FP64 arithmetic on either side is below 1e-12 of these magnitudes.  kScreenSlack rounds all of it up.

@@ -102,10 +102,11 @@ struct CloudSet {
     bool split_ready = false;          // built on first selection of that kernel
     std::vector<int> group_off;        // n_clouds + 1
     std::vector<double> centres;       // n_clouds * 3
-    DevBuf bound_dev;                  // per cloud: radius_mean and rot_norm (1 + 1e-9), for the screening budget
+    DevBuf bound_dev;                  // per cloud, kCloudBound doubles: radius_mean, rot_norm (1 + 1e-9), radius_axis[3]: the screening budget's inputs
     DevBuf radius_dev;                 // per cloud: bits of the largest squared distance from the centre
     std::vector<double> radius;        // per cloud: that distance (infinity if a point is not finite)
     std::vector<double> radius_mean;   // per cloud: mean distance from the centre (same convention)
+    std::vector<double> radius_axis;   // per cloud: mean |x - cx|, |y - cy|, |z - cz| (same convention)
     std::vector<double> rot_norm;      // per cloud: bound on the 2-norm of the robot pose's 3x3 part
     int64_t n_groups = 0;
     int64_t n_pad_points = 0;          // zero points added to fill the last groups
@@ -264,6 +265,9 @@ hipError_t static_scratch_address(double** out);
 // A result array of the context's stream into the caller's (pageable) memory, through the
 // pinned staging lanes when it is large; returns with the bytes in place.
 hipError_t download_array(ccal_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+// Makes the request buffers of the exact and screening paths for a freshly uploaded set (api_exact.hip).
+int presize_request_buffers(ccal_ctx* ctx, const CloudSet& cs);
 
 // allow_split: the poses are close to those of the previous such call (a descent), so a small request
 // may cut its chains into parts whose units are guessed from that call's sums (same values either way).

@@ -67,6 +67,7 @@ struct BlockDesc {
 // Per (pose, cloud): rows 0..2 of M = base_T_flange_j * F(pose), 12 doubles.
 // Per pose: plane a,b,c,d, sqrt(a^2+b^2+c^2), its rounded reciprocal and a flag
 // (non-zero when the norm is in the range the reciprocal path covers), padded to 8.
+constexpr int kCloudBound = 5;     // doubles per cloud of the screening budget's table: mean radius, norm bound, mean |dx|, |dy|, |dz|
 constexpr int kPlaneStride = 8;
 
 __device__ inline double exact_distance(const double* M, const double* pl, float x, float y,

@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
                                                          float* __restrict__ xs, float* __restrict__ ys,
                                                          float* __restrict__ zs, float* __restrict__ groups,
                                                          unsigned int* __restrict__ radius2_bits /* this cloud */,
-                                                         float* __restrict__ radius_sums /* this cloud: one per block */)
+                                                         float* __restrict__ radius_sums /* this cloud: four per block */)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const double cx = centre[0], cy = centre[1], cz = centre[2];
-    float r2 = 0.f;
+    float r2 = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
     if (i < n) {
         const float x = aos[3 * i + 0], y = aos[3 * i + 1], z = aos[3 * i + 2];
         xs[first_point + i] = x;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
         // lane l = k*16 + col holds coordinate k; component u selects the tile
         const float dx = (float)((double)x - cx), dy = (float)((double)y - cy), dz = (float)((double)z - cz);
         r2 = dx * dx + dy * dy + dz * dz;
+        ax = __builtin_fabsf(dx); ay = __builtin_fabsf(dy); az = __builtin_fabsf(dz);
         const int64_t src = fast_slot_source(i, n, stride);
         const float sx = aos[3 * src + 0], sy = aos[3 * src + 1], sz = aos[3 * src + 2];
         gp[(0 * 16 + col) * 4 + u] = (float)((double)sx - cx);
@@ -102,11 +103,15 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
     }
     // largest squared distance from the centre: non-negative floats order like their bit patterns,
     // and a NaN's pattern lies above infinity's, so a non-finite point leaves a non-finite mark
-    // sum of the distances from the centre, per block in a fixed order (the host adds the blocks)
-    __shared__ float wave_sums[4];
-    float rs = __builtin_sqrtf(r2);
-    for (int off = 32; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
-    if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6] = rs;
+    // sums of the distances from the centre and of their components along the cloud's axes, per block in a
+    // fixed order (the host adds the blocks)
+    __shared__ float wave_sums[4][4];
+    float rs[4] = {__builtin_sqrtf(r2), ax, ay, az};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        for (int off = 32; off > 0; off >>= 1) rs[k] += __shfl_xor(rs[k], off, 64);
+        if ((threadIdx.x & 63) == 0) wave_sums[threadIdx.x >> 6][k] = rs[k];
+    }
     __shared__ unsigned int wave_bits[4];
     unsigned int bits = __float_as_uint(r2);
     for (int off = 32; off > 0; off >>= 1) {
@@ -118,7 +123,9 @@ __global__ __launch_bounds__(256) void tile_cloud_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) bits = wave_bits[w] > bits ? wave_bits[w] : bits;
         atomicMax(radius2_bits, bits);
-        radius_sums[blockIdx.x] = ((wave_sums[0] + wave_sums[1]) + wave_sums[2]) + wave_sums[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            radius_sums[4 * (int64_t)blockIdx.x + k] = ((wave_sums[0][k] + wave_sums[1][k]) + wave_sums[2][k]) + wave_sums[3][k];
     }
 }
 

@@ -864,6 +864,31 @@ def test_screening_bound_holds_and_is_tight_enough(gpu_opt):
         fast, bound = gpu_opt.get_error_bounded(poses)
         exact = gpu_opt.get_error(poses)
         assert np.all(np.abs(fast - exact) <= bound), (trial, scale)
+    # thin slabs in arbitrary orientation (what a depth camera sees of a plane): the budget weighs the cloud's
+    # mean extent along each of its own axes, so extents that differ by decades between the axes, rotated
+    # against the plane in every which way, are what could catch it out
+    worst = 0.0
+    for trial in range(40):
+        scale = 10.0 ** rng.uniform(-2, 1)
+        n_clouds = int(rng.integers(1, 5))
+        clouds = []
+        for _ in range(n_clouds):
+            axes = scale * 10.0 ** rng.uniform(-4, 0, 3)
+            q, _ = np.linalg.qr(rng.normal(0, 1, (3, 3)))
+            pts = (rng.normal(0, 1, (int(rng.integers(1, 9000)), 3)) * axes) @ (q if trial % 2 else np.eye(3))
+            clouds.append((pts + rng.normal(0, 3 * scale, 3)).astype(np.float32))
+        B = np.stack([__import__("cameracalibration_amd").pose_to_matrix(
+            np.concatenate([rng.normal(0, scale, 3), rng.uniform(-3, 3, 3)])).reshape(16) for _ in range(n_clouds)])
+        gpu_opt.upload_clouds(0, clouds, B)
+        plane = rng.normal(0, 1, 4)
+        plane[3] *= scale
+        gpu_opt.set_plane(plane)
+        poses = np.concatenate([rng.normal(0, scale, (20, 3)), rng.uniform(-3, 3, (20, 3))], axis=1)
+        fast, bound = gpu_opt.get_error_bounded(poses)
+        exact = gpu_opt.get_error(poses)
+        assert np.all(np.abs(fast - exact) <= bound), (trial, scale)
+        worst = max(worst, float(np.max(np.abs(fast - exact) / bound)))
+    assert worst < 0.5, worst        # roundings do not all point the same way: the bound is never close
     # a non-finite point: no bound
     clouds[0][0, 1] = np.nan
     gpu_opt.upload_clouds(0, clouds, B)
