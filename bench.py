@@ -522,8 +522,11 @@ def main():
                                          "screen_prep+cost+reduce": pr.screen_ms},
                     # where an iteration's wall time goes (this profiled descent): device time of the
                     # kernels, host time before and after the stream waits, and the waits themselves
+                    # ("wall" is this profiled run's: with the timers on, the waits go through stream events;
+                    # "wall_unprofiled" is the descent timed for time_to_converged, which watches the result words)
                     "us_per_iteration": {
                         "wall": (t_p1 - t_p0) * 1e6 / max(r_p.iterations, 1),
+                        "wall_unprofiled": (t3 - t2) * 1e6 / max(r.iterations, 1),
                         "split_chain_kernel": pr.split_chain_ms * 1e3 / max(r_p.iterations, 1),
                         "split_finish_kernel": pr.split_finish_ms * 1e3 / max(r_p.iterations, 1),
                         "screening_kernels": pr.screen_ms * 1e3 / max(r_p.iterations, 1),
