@@ -245,7 +245,18 @@ def main():
     xdev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        # gloo announces its connections on the process's standard output; this program's standard output
+        # carries one JSON line and nothing else, so the announcements go to standard error
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def barrier():
         if world > 1:
