@@ -356,9 +356,9 @@ int ccal::exact_wait_rest(ccal_ctx* ctx, double* cost, double* per_cloud_mean, d
         }
     }
     cs.seg_sums_valid = true;
-    if (!job.want_max || !job.split) {
-        // the request's last pose left its running sums behind (both kinds of kernel); its totals, for callers
-        // that want to say how far the next request's chains are from them
+    {
+        // the request's last pose left its running sums behind (both kinds of kernel do that); its totals, for
+        // callers that want to say how far the next request's chains are from them
         const double* hs = ctx->exact_out.as<double>() + (size_t)(job.nb - 1) * C;
         cs.seg_ref_totals.assign(hs, hs + C);
     }
