@@ -191,8 +191,8 @@ def north_star(cc, opt, scene, grid3, upload_s, args):
         "achieved": rate * MATRIX_FLOP_PER_RESIDUAL["bf16x3"] / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": rate * MATRIX_FLOP_PER_RESIDUAL["bf16x3"] / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
         "pipe": "dense bf16 matrix pipe (operands as exact three-way bf16 splits, as the residual kernel); one "
-                "(hypothesis, point) test = one K=4 contraction and two threshold compares; the compares and "
-                "add-with-carries on the vector unit (16 per matrix instruction) set the pace, not the pipe",
+                "(hypothesis, point) test = one K=4 contraction and one threshold compare; the compares and "
+                "add-with-carries on the vector unit (8 per matrix instruction) set the pace, not the pipe",
         # the yardstick of the task: 8 algorithmic FLOP per test against the FP32 (vector = FP32-input matrix) peak
         "algorithmic_fp32": {"flop_per_test": FLOP_PER_RESIDUAL, "achieved": rate * FLOP_PER_RESIDUAL / 1e12,
                              "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "ratio": rate * FLOP_PER_RESIDUAL / 1e12 / PEAK_FP32_TFLOPS},

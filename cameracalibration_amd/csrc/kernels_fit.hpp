@@ -133,26 +133,24 @@ __global__ __launch_bounds__(1024) void moments_finalize_kernel(const double* __
 
 // The residual contraction of the search, counting instead of summing (RANSAC scoring).  The FP32 residual
 // of a point lies within a known distance e of the reference-arithmetic one (the caller derives e per
-// cloud), so two counts bracket the reference's inlier count of a hypothesis: points with |w.p| < thr - e
-// are inliers for certain, points with |w.p| >= thr + e are not.  thr_tab[cloud] = (thr - e, thr + e),
-// rounded outwards.  partial[0][split][candidate] = certain, partial[1][split][candidate] = possible.
-// Padding points have residual 0 and are counted wherever 0 lies below the bound; the host
-// subtracts them.  Lane counters are 32 bits wide: a lane sees 1/16 of a split's points.
+// cloud), so a point with |w.p| >= thr + e is no inlier of the reference's count: the points below that
+// mark bound a hypothesis's inlier count from above.  thr_tab[cloud][1] = thr + e, rounded upwards
+// ([0] = thr - e is not used here).  partial[split][candidate] = the possible inliers.  The caller re-counts
+// exactly what these bounds cannot exclude; a second counter for the points below thr - e (a lower
+// bound, which an earlier form of this kernel kept) only chose which hypotheses to re-count first and
+// doubled the kernel's vector instructions.
+// Padding points have residual 0 and are counted; the host subtracts them.  Lane counters are 32 bits
+// wide: a lane sees 1/16 of a split's points.
 //
 // The contraction runs on the bf16 matrix pipe with both FP32 operands as exact three-way bf16 splits
 // (bf16x3_split.hpp), as in residual_bf16x3_kernel: the matrix instruction then issues in the shadow of
-// the sixteen compare / add-carry instructions that each result costs, which bound the kernel either way
-// (with the FP32-input instruction, which shares the vector unit's issue port, the two added up:
-// 74.6 ms per 4096 hypotheses x 10^8 points).
+// the eight compare / add-carry instructions that each result costs, which bound the kernel either way
+// (with the FP32-input instruction, which shares the vector unit's issue port, the two added up).
 template <int NA>
-__device__ inline void count_brackets(const f32x4& d, float tlo, float thi, unsigned int (&lo)[4], unsigned int (&hi)[4])
+__device__ inline void count_possible(const f32x4& d, float thi, unsigned int (&hi)[4])
 {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float m = __builtin_fabsf(d[r]);
-        lo[r] += (m < tlo) ? 1u : 0u;
-        hi[r] += (m < thi) ? 1u : 0u;
-    }
+    for (int r = 0; r < 4; ++r) hi[r] += (__builtin_fabsf(d[r]) < thi) ? 1u : 0u;
 }
 
 template <int NA>
@@ -169,11 +167,11 @@ __global__ __launch_bounds__(256, 2) void inlier_mfma_kernel(
     constexpr int kBurst = 4;
     static_assert(NA % kBurst == 0, "candidate tiles per wave must be a multiple of the burst");
 
-    unsigned int lo[NA][4], hi[NA][4];
+    unsigned int hi[NA][4];
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { lo[a][r] = 0; hi[a][r] = 0; }
+        for (int r = 0; r < 4; ++r) hi[a][r] = 0;
 
     for (int j = 0; j < n_clouds; ++j) {
         const int g0 = group_off[j];
@@ -181,8 +179,7 @@ __global__ __launch_bounds__(256, 2) void inlier_mfma_kernel(
         const int gb = g0 + (int)(((int64_t)G * split) / n_splits);
         const int ge = g0 + (int)(((int64_t)G * (split + 1)) / n_splits);
         if (gb >= ge) continue;
-        const f32x2 t = thr_tab[j];
-        const float tlo = t[0], thi = t[1];
+        const float thi = thr_tab[j][1];
         bf16x8 A[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a)
@@ -215,9 +212,9 @@ __global__ __launch_bounds__(256, 2) void inlier_mfma_kernel(
                     for (int q = 0; q < kBurst; ++q) {
                         const f32x4 done = i0 == 0 ? carry[q] : d[i0 == 0 ? 0 : i0 - kBurst + q];
                         const int a = (i0 + 4 * NA - kBurst + q) % NA;
-                        count_brackets<NA>(done, tlo, thi, lo[a], hi[a]);
+                        count_possible<NA>(done, thi, hi[a]);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 16 * kBurst + 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8 * kBurst + 5, 0);
                 }
                 Bc = Bn;
             }
@@ -226,24 +223,19 @@ __global__ __launch_bounds__(256, 2) void inlier_mfma_kernel(
             b = bn;
         }
 #pragma unroll
-        for (int q = 0; q < kBurst; ++q) count_brackets<NA>(carry[q], tlo, thi, lo[NA - kBurst + q], hi[NA - kBurst + q]);
+        for (int q = 0; q < kBurst; ++q) count_possible<NA>(carry[q], thi, hi[NA - kBurst + q]);
     }
-    const int64_t plane = (int64_t)n_splits * n_ctiles * 16;
     unsigned long long* out = partial + (int64_t)split * n_ctiles * 16;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            unsigned long long v = lo[a][r], w = hi[a][r];
-            v += __shfl_xor(v, 1, 64); w += __shfl_xor(w, 1, 64);
-            v += __shfl_xor(v, 2, 64); w += __shfl_xor(w, 2, 64);
-            v += __shfl_xor(v, 4, 64); w += __shfl_xor(w, 4, 64);
-            v += __shfl_xor(v, 8, 64); w += __shfl_xor(w, 8, 64);
-            if ((lane & 15) == 0) {
-                const int64_t at = (int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r;
-                out[at] = v;
-                out[plane + at] = w;
-            }
+            unsigned long long w = hi[a][r];
+            w += __shfl_xor(w, 1, 64);
+            w += __shfl_xor(w, 2, 64);
+            w += __shfl_xor(w, 4, 64);
+            w += __shfl_xor(w, 8, 64);
+            if ((lane & 15) == 0) out[(int64_t)(ctile0 + a) * 16 + (lane >> 4) * 4 + r] = w;
         }
 }
 

@@ -122,7 +122,6 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
         if (!(Q[j] <= Qmax)) Qmax = Q[j];      // a NaN or infinity sticks
     }
     std::vector<f32x2> thr_tab((size_t)C);
-    int64_t n_pad_lo = 0;
     for (int j = 0; j < C; ++j) {
         const double rn = cs.rot_norm[j] * (1.0 + 1e-9);
         double e = kSlack * u24 * (Q[j] + 71.0 * (rn * cs.radius[j] + mj[j] + Qmax)) + 1e-30;
@@ -134,14 +133,12 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
         if (!((double)lo <= (double)threshold - e)) lo = -std::numeric_limits<float>::infinity();
         if (!((double)hi >= (double)threshold + e)) hi = std::numeric_limits<float>::infinity();
         thr_tab[j] = f32x2{lo, hi};
-        const int64_t pad = (int64_t)(cs.group_off[j + 1] - cs.group_off[j]) * kGroupPoints - (int64_t)cs.n_pts[j];
-        if (lo > 0.f) n_pad_lo += pad;          // a padding point has residual exactly 0
     }
     FastLaunch f = plan_fast(ctx, cs, n_hyp, kCandPerBlock);
     const size_t part_words = (size_t)f.n_splits * f.n_padded;
     CCAL_HIP(ctx, ctx->w_buf.ensure((size_t)C * f.n_ctiles * 64 * sizeof(float)));
-    CCAL_HIP(ctx, ctx->partial_buf.ensure(2 * part_words * sizeof(unsigned long long)));
-    CCAL_HIP(ctx, ctx->cost_buf.ensure(2 * (size_t)n_hyp * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->partial_buf.ensure(part_words * sizeof(unsigned long long)));
+    CCAL_HIP(ctx, ctx->cost_buf.ensure((size_t)n_hyp * sizeof(unsigned long long)));
     CCAL_HIP(ctx, ctx->tbl_buf.ensure(thr_tab.size() * sizeof(f32x2)));
     CCAL_HIP(ctx, hipMemcpyAsync(ctx->tbl_buf.p, thr_tab.data(), thr_tab.size() * sizeof(f32x2),
                                  hipMemcpyHostToDevice, ctx->stream));
@@ -155,12 +152,11 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
                        cs.group_off_dev.as<int>(), ctx->partial_buf.as<unsigned long long>(),
                        ctx->tbl_buf.as<f32x2>(), C, f.n_ctiles, f.n_splits);
     if (ctx->profiling) CCAL_HIP(ctx, hipEventRecord(ctx->prof_ev[1], ctx->stream));
-    for (int k = 0; k < 2; ++k)
-        hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
-                           ctx->stream, ctx->partial_buf.as<unsigned long long>() + k * part_words, f.n_padded,
-                           f.n_splits, (int64_t)n_hyp, ctx->cost_buf.as<unsigned long long>() + (size_t)k * n_hyp);
+    hipLaunchKernelGGL(reduce_splits_u64_kernel, dim3((n_hyp + 255) / 256), dim3(256), 0,
+                       ctx->stream, ctx->partial_buf.as<unsigned long long>(), f.n_padded,
+                       f.n_splits, (int64_t)n_hyp, ctx->cost_buf.as<unsigned long long>());
     CCAL_HIP(ctx, hipGetLastError());
-    std::vector<unsigned long long> fast(2 * (size_t)n_hyp);
+    std::vector<unsigned long long> fast((size_t)n_hyp);
     std::vector<double> planes((size_t)n_hyp * kHypStride);
     CCAL_HIP(ctx, hipMemcpyAsync(fast.data(), ctx->cost_buf.p, fast.size() * sizeof(unsigned long long),
                                  hipMemcpyDeviceToHost, ctx->stream));
@@ -176,31 +172,24 @@ extern "C" int ccal_ransac_plane(ccal_ctx* ctx, int which, const double pose[6],
         }
     }
 
-    // certain[h] <= (reference-arithmetic inlier count of h) <= possible[h].  Invalid (collinear)
-    // hypotheses have w = 0 and count everything: drop them.
-    unsigned long long* certain = fast.data();
-    unsigned long long* possible = fast.data() + n_hyp;
+    // (reference-arithmetic inlier count of h) <= possible[h].  Invalid (collinear) hypotheses have
+    // w = 0 and count everything: drop them.
+    unsigned long long* possible = fast.data();
     std::vector<int> order;
-    unsigned long long best_certain = 0;
     for (int h = 0; h < n_hyp; ++h) {
         if (planes[(size_t)h * kHypStride + 5] == 0.0) continue;
-        certain[h] -= (unsigned long long)n_pad_lo;
         possible[h] -= (unsigned long long)cs.n_pad_points;
-        best_certain = std::max(best_certain, certain[h]);
         order.push_back(h);
     }
     if (order.empty()) return fail(ctx, CCAL_ERR_ARG, "ransac_plane: every sample was collinear");
 
-    // 3. exact recount.  Only a hypothesis whose possible count reaches the best certain count can
-    // hold the most inliers; those are re-counted with the reference arithmetic, kRecount per pass
-    // over the points: first the ones with the highest certain counts, which sets a high mark, then
-    // -- in index order -- whatever that mark (most inliers so far, lowest index on ties) still
-    // cannot exclude.
-    std::vector<int> leaders;
-    for (int h : order)
-        if (possible[h] >= best_certain) leaders.push_back(h);
+    // 3. exact recount, kRecount hypotheses per pass over the points, with the reference arithmetic.
+    // First the ones with the highest bounds (lowest index first among equals), which sets a high mark;
+    // then -- in index order -- whatever that mark (most inliers so far, lowest index on ties) still cannot
+    // exclude: a hypothesis whose bound is below the mark, or equal to it at a higher index, cannot win.
+    std::vector<int> leaders = order;
     std::stable_sort(leaders.begin(), leaders.end(),
-                     [&](int a, int b) { return certain[a] > certain[b]; });
+                     [&](int a, int b) { return possible[a] > possible[b]; });
     std::vector<int> rest;
     if (leaders.size() > (size_t)kRecount) {
         rest.assign(leaders.begin() + kRecount, leaders.end());
