@@ -378,8 +378,20 @@ __global__ __launch_bounds__(256) void exact_count_kernel(
             __syncthreads();
             cloud = bd.cloud;
         }
-        for (int64_t i = bd.begin + threadIdx.x; i < bd.end; i += blockDim.x) {
-            const double xd = (double)xs[i], yd = (double)ys[i], zd = (double)zs[i];
+        // four points of a thread in flight: a trip of one load and its arithmetic was all latency
+        constexpr int kInFlight = 4;
+        for (int64_t base = bd.begin + threadIdx.x; base < bd.end; base += (int64_t)kInFlight * blockDim.x) {
+          float px[kInFlight], py[kInFlight], pz[kInFlight];
+#pragma unroll
+          for (int u = 0; u < kInFlight; ++u) {
+              const int64_t i = base + (int64_t)u * blockDim.x;
+              const bool in = i < bd.end;
+              px[u] = in ? xs[i] : 0.f; py[u] = in ? ys[i] : 0.f; pz[u] = in ? zs[i] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < kInFlight; ++u) {
+            if (base + (int64_t)u * blockDim.x >= bd.end) break;
+            const double xd = (double)px[u], yd = (double)py[u], zd = (double)pz[u];
             double q[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -401,6 +413,7 @@ __global__ __launch_bounds__(256) void exact_count_kernel(
                     cnt[k] += d < thr ? 1u : 0u;
                 }
             }
+          }
         }
     }
 #pragma unroll
